@@ -1,0 +1,328 @@
+/*
+ * tracevae_hip.h - C-ABI of libtracevae_hip.so: the MI355X (gfx950) kernels behind the
+ * TraceVAE training / scoring path.
+ *
+ * The reference (NetManAIOps/TraceVAE) is pure Python and has no FFI of its own: its seam
+ * is the Python model API, and the arithmetic is done by DGL / PyTorch operators called
+ * from Python.  Every entry point below therefore cites the reference *call site* (file:line
+ * under /root/reference) whose DGL / torch / tensorkit operator it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless the
+ *     comment says "host";
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - the caller owns every buffer: kernels never allocate, workspaces are caller-provided
+ *     and their sizes come from the matching *_workspace_bytes call;
+ *   - return value: 0 = ok, <0 = error (TV_ERR_*); tv_last_error() gives the text for the
+ *     calling thread.  Shapes are validated on the host before any launch;
+ *   - every reduction is a fixed-order segmented / two-stage reduction: no float atomics,
+ *     results are bitwise reproducible run to run;
+ *   - index arrays are int64 (DGL's default idtype), features are float32.
+ */
+#ifndef TRACEVAE_HIP_H
+#define TRACEVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TV_OK 0
+#define TV_ERR_INVALID (-1) /* bad argument / shape */
+#define TV_ERR_LAUNCH (-2)  /* HIP reported a launch error */
+#define TV_ERR_WORKSPACE (-3) /* workspace too small */
+
+/* status bits written by tv_batch_build into *status (device int32) */
+#define TV_BATCH_TOO_MANY_NODES 1 /* a trace has more than max_node_count nodes           */
+#define TV_BATCH_BAD_EDGE 2       /* an edge violates 0 <= u < v < n                        */
+#define TV_BATCH_MISSING_LATENCY_RANGE 4 /* operation without (mean,std): reference KeyError */
+#define TV_BATCH_BAD_NODE_TYPE 8  /* node_type outside [0, num_operations)                  */
+
+const char *tv_last_error(void);
+int tv_version(void);
+
+/* number of partial-result slots the two-stage column reductions use for `rows` rows */
+int64_t tv_stat_blocks(int64_t rows);
+
+/* ------------------------------------------------------------------------------------
+ * (a) batching: collated trace graphs -> device-side COO + destination-sorted CSC
+ *
+ * Replaces trace_graph_to_dgl (tracegnn/models/trace_vae/dataset.py:20-89: dgl.graph +
+ * add_self_loop + ndata + latency normalisation), TraceGraphBatch.build_dgl
+ * (types.py:42-62: dgl.batch(...).to(device)), dense_triu_adj + dense_to_triu
+ * (tensor_utils.py:79-89, 64-67; stacked at model/trace_vae.py:122-132),
+ * pad_node_feature (tensor_utils.py:92-114; model/trace_vae.py:134-140) and the padded
+ * decoder graph rebuilt on every p() call (model/struct_vae.py:335-362).
+ *
+ * Input: a trace store in HBM (concatenated per-trace arrays; u, v are trace-local node
+ * ids with u < v) and, for the B traces of this batch, where each one starts in the store.
+ * Trace i has n_i = node_offsets[i+1]-node_offsets[i] nodes and n_i-1 edges.
+ *
+ * Output (N = node_offsets[B], E_enc = 3N-2B, E_dec = B*M + 2(N-B)):
+ *   enc_src/enc_dst [E_enc]  COO in DGL edge-id order: per trace [u->v ; v->u ; self x n]
+ *   enc_indptr [N+1], enc_indices [E_enc] (=src), enc_eids [E_enc]: stable sort by dst
+ *   enc_rev [E_enc]: CSC position of the opposite edge (used by the backward pass)
+ *   dec_*: the same for the decoder graph, every trace padded to M nodes:
+ *          per trace [u->v ; v->u ; self x M], node ids i*M + local
+ *   adj [B, M(M-1)/2] f32, node_type_pad [B,M] i64, latency_pad [B,M] f32 (avg latency),
+ *   node_count [B] i64, node_type [N] i64, latency [N,3] f32 (avg,min,max normalised as
+ *   float32((double(x) - mean[op]) / (std[op] + 1e-5))), graph_id [N] i64.
+ * ---------------------------------------------------------------------------------- */
+int tv_batch_build(int64_t batch, int64_t max_node_count, int64_t total_nodes,
+                   int64_t num_operations,
+                   const int64_t *node_offsets,   /* [B+1] batch-local, node_offsets[0]=0 */
+                   const int64_t *store_node_start, /* [B] */
+                   const int64_t *store_edge_start, /* [B] */
+                   const int64_t *store_u, const int64_t *store_v,
+                   const int64_t *store_node_type, const float *store_avg_latency,
+                   const float *store_min_latency, const float *store_max_latency,
+                   const double *latency_mean, const double *latency_std, /* [V], NaN = missing */
+                   int64_t *enc_src, int64_t *enc_dst, int64_t *enc_indptr,
+                   int64_t *enc_indices, int64_t *enc_eids, int64_t *enc_rev,
+                   int64_t *dec_src, int64_t *dec_dst, int64_t *dec_indptr,
+                   int64_t *dec_indices, int64_t *dec_eids, int64_t *dec_rev, float *adj,
+                   int64_t *node_type_pad, float *latency_pad, int64_t *node_count,
+                   int64_t *node_type, float *latency, int64_t *graph_id,
+                   int32_t *status, /* device int32, OR-ed TV_BATCH_* bits; caller zeroes it */
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * dense layers: C[M,N] = row_scale[m] * (op(A)[M,K] . op(B)[K,N]) + bias[n]
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+ * row-major storage; transX = 0: stored as written, 1: stored transposed.
+ *
+ * Replaces nn.Linear inside dgl.nn.GATConv.fc (model/gnn_layers.py:134-143), the matmul
+ * of dgl.nn.GraphConv (gnn_layers.py:173-183), tk.layers.Linear / Dense
+ * (model/struct_vae.py:139-180, model/latency_vae.py:181-203) and their autograd
+ * backward (dX = dY.W, dW = dY^T.X use the same kernel with other trans flags; a
+ * reduction over many rows is split over K with a fixed-order second-stage sum).
+ * bias / row_scale may be NULL.  accumulate != 0 adds into C.
+ * ---------------------------------------------------------------------------------- */
+int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
+                int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc,
+                const float *bias, const float *row_scale, int accumulate, void *workspace,
+                int64_t workspace_bytes, void *stream);
+
+/* skinny right-hand side (N <= 8): out[r,j] = row_scale[r] * sum_k x[r,k] w[k,j]  (w is [K,N])
+ * Replaces the 1000->2 GraphConv matmul of the latency decoder (model/latency_vae.py:221-229,
+ * DGL multiplies by W before aggregating when in > out). */
+int tv_rowdot_fwd(int64_t rows, int64_t k, int64_t n, const float *x, const float *w,
+                  const float *row_scale, float *out, void *stream);
+int64_t tv_rowdot_bwd_workspace_bytes(int64_t rows, int64_t k, int64_t n);
+int tv_rowdot_bwd(int64_t rows, int64_t k, int64_t n, const float *x, const float *w,
+                  const float *row_scale, const float *dout, float *dx /* nullable */,
+                  float *dw /* [K,N] */, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* column sums: out[c] = sum_r x[r,c]  (bias gradients).  Two-stage, fixed order. */
+int64_t tv_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int tv_colsum(int64_t rows, int64_t cols, const float *x, int64_t ldx, float *out,
+              void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * (b) GAT message passing over the destination-sorted CSC.
+ * The graph may be replicated `n_rep` times block-diagonally (test-time K samples):
+ * row r = rep * rows_per_rep + v uses the CSC of node v, neighbours offset by rep*rows_per_rep.
+ *
+ * tv_gat_scores: el[r,h] = sum_f ft[r,h,f] attn_l[h,f], er likewise
+ *   (the (ft*attn).sum(-1) of dgl.nn.GATConv; call site model/gnn_layers.py:143).
+ * tv_gat_aggregate_fwd: e = LeakyReLU_0.2(el[src]+er[dst]); a = softmax over the in-edges
+ *   of dst; out[dst] = sum a * ft[src] + bias   (apply_edges + edge_softmax + update_all of
+ *   GATConv, gnn_layers.py:143), heads concatenated as [rows, H*F] (gnn_layers.py:144-148).
+ *   alpha [n_rep * E, H] is kept in CSC order for the backward pass (NULL to skip).
+ *   Optional fused epilogues:
+ *     stats_partial != NULL : per-block column sum / sum of squares of `out`
+ *                             [tv_stat_blocks(rows), 2, H*F] for the BatchNorm that follows
+ *                             (gnn_layers.py:152-153, training mode);
+ *     ep_scale/ep_shift != NULL : y = LeakyReLU_slope(out*ep_scale + ep_shift) written to
+ *                             `out` instead (eval-mode BatchNorm + activation, :152-155).
+ * tv_gat_aggregate_bwd: gradients w.r.t. ft, attn_l, attn_r, bias given d(out).
+ * ---------------------------------------------------------------------------------- */
+int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const float *ft,
+                  const float *attn_l, const float *attn_r, float *el, float *er, void *stream);
+int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
+                         const int64_t *indptr, const int64_t *indices, const float *ft,
+                         const float *el, const float *er, const float *bias, float *out,
+                         float *alpha, float *stats_partial, const float *ep_scale,
+                         const float *ep_shift, float ep_slope, void *stream);
+int64_t tv_gat_aggregate_bwd_workspace_bytes(int64_t rows_per_rep, int64_t n_rep,
+                                             int64_t heads, int64_t feats, int64_t num_edges);
+int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
+                         int64_t num_edges, const int64_t *indptr, const int64_t *indices,
+                         const int64_t *rev, const float *ft, const float *el, const float *er,
+                         const float *attn_l, const float *attn_r, const float *alpha,
+                         const float *dout, float *dft, float *dattn_l, float *dattn_r,
+                         float *dbias, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm over rows + LeakyReLU (tk.layers.BatchNorm = torch BatchNorm1d, then
+ * tk.layers.LeakyReLU; model/gnn_layers.py:152-155 and every `dense` of the MLPs,
+ * model/struct_vae.py:117-120).
+ *   tv_colstats        : partial[nblk,2,C] = per-block column sum / sum of squares
+ *   tv_bn_finalize     : mean, rstd (biased variance) from the partials, in float64;
+ *                        running_mean/var updated with `momentum` (unbiased variance)
+ *   tv_bn_apply_lrelu  : y = LeakyReLU_slope((x-mean)*rstd*gamma + beta)
+ *   tv_affine_lrelu    : y = LeakyReLU_slope(x*scale + shift)   (eval mode, folded stats)
+ *   tv_bn_eval_coeffs  : scale = gamma/sqrt(var+eps), shift = beta - mean*scale
+ *   tv_bn_lrelu_bwd    : dx, dgamma, dbeta given dy (training mode: batch statistics)
+ *   tv_affine_lrelu_bwd: dx = dy * lrelu'(x*scale+shift) * scale (eval mode inside a
+ *                        training step: phase 2 of train.py:204-208)
+ * ---------------------------------------------------------------------------------- */
+int tv_colstats(int64_t rows, int64_t cols, const float *x, float *partial, void *stream);
+int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, int64_t count, float eps,
+                   float momentum, float *mean, float *rstd, float *running_mean,
+                   float *running_var, void *stream);
+int tv_bn_apply_lrelu(int64_t rows, int64_t cols, const float *x, const float *mean,
+                      const float *rstd, const float *gamma, const float *beta, float slope,
+                      float *y, void *stream);
+int tv_bn_eval_coeffs(int64_t cols, const float *running_mean, const float *running_var,
+                      const float *gamma, const float *beta, float eps, float *scale,
+                      float *shift, void *stream);
+int tv_affine_lrelu(int64_t rows, int64_t cols, const float *x, const float *scale,
+                    const float *shift, float slope, float *y, void *stream);
+int64_t tv_bn_lrelu_bwd_workspace_bytes(int64_t rows, int64_t cols);
+int tv_bn_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float *dy,
+                    const float *mean, const float *rstd, const float *gamma, const float *beta,
+                    float slope, float *dx, float *dgamma, float *dbeta, void *workspace,
+                    int64_t workspace_bytes, void *stream);
+int tv_affine_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float *dy,
+                        const float *scale, const float *shift, float slope, float *dx,
+                        void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * GraphConv(norm='both') aggregation: out[v] = sum_{u in in(v)} x[u] * deg(u)^-1/2
+ * (degrees include the self loop, clamp >= 1), optionally followed by * deg(v)^-1/2.
+ * The graph is symmetric, so the backward pass is the same kernel with the roles of the
+ * two scalings swapped.  Replaces the update_all(copy_u, sum) of dgl.nn.GraphConv
+ * (model/gnn_layers.py:173-183; final decoder layers model/struct_vae.py:201-206,
+ * model/latency_vae.py:221-229).
+ * ---------------------------------------------------------------------------------- */
+int tv_graph_sum(int64_t rows_per_rep, int64_t n_rep, int64_t cols, const int64_t *indptr,
+                 const int64_t *indices, const float *x, int scale_src, int scale_dst,
+                 float *out, void *stream);
+/* deg^-1/2 per row of the (replicated) graph, for the GEMM row_scale epilogue */
+int tv_graph_norm(int64_t rows_per_rep, int64_t n_rep, const int64_t *indptr, float *norm,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * graph readout: dgl.nn.AvgPooling (model/pooling.py:45) = per-trace mean of node rows
+ * ---------------------------------------------------------------------------------- */
+int tv_segment_mean_fwd(int64_t batch, int64_t cols, const int64_t *node_offsets,
+                        const float *x, float *out, void *stream);
+int tv_segment_mean_bwd(int64_t rows, int64_t cols, const int64_t *node_offsets,
+                        const int64_t *graph_id, const float *dout, float *dx, void *stream);
+
+/* operation embedding: torch.nn.Embedding row gather (model/operation_embedding.py:21-25)
+ * written into columns [col0, col0+dim) of a [rows, ld] buffer; bwd: deterministic
+ * per-operation segmented sum. */
+int tv_embedding_fwd(int64_t rows, int64_t dim, int64_t num_operations, const float *weight,
+                     const int64_t *ids, float *out, int64_t ld, int64_t col0, void *stream);
+int tv_embedding_bwd(int64_t rows, int64_t dim, int64_t num_operations, const int64_t *ids,
+                     const float *dout, int64_t ld, int64_t col0, float *dweight, void *stream);
+
+/* latency-decoder input rows [z2 (broadcast over the M slots) || emb[node_type_pad]]
+ * (model/latency_vae.py:320-343): out [K*B*M, Z2+E]; bwd: dz2[k,b,:] = sum_m d(out)[..., :Z2] */
+int tv_latdec_input_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count, int64_t z2_dim,
+                        int64_t emb_dim, int64_t num_operations, const float *z2,
+                        const float *emb_weight, const int64_t *node_type_pad, float *out,
+                        void *stream);
+int tv_latdec_input_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count, int64_t z2_dim,
+                        int64_t emb_dim, const float *dout, float *dz2, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * (c)/(d) likelihoods
+ * ---------------------------------------------------------------------------------- */
+/* p(adj|z): edge_logits_by_dot_product + dense_to_triu + Bernoulli(event_ndims=1) log-prob
+ * (tensor_utils.py:54-67, model/struct_vae.py:281-294), never materialising [K,B,M,M]:
+ * ll[k,b] = sum_{i<j} f(adj*l - softplus(l)), l = <h[k,b,i,:], h[k,b,j,:]>,
+ * f(x) = x < log(threshold) ? alpha*x : x when biased (distributions.py:125-134).
+ * bwd: dh given d(ll). */
+int tv_adj_bernoulli_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
+                            int64_t dim, const float *h, const float *adj, int biased,
+                            float alpha, float log_threshold, float *ll, void *stream);
+int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
+                            int64_t dim, const float *h, const float *adj, int biased,
+                            float alpha, float log_threshold, const float *dll, float *dh,
+                            void *stream);
+
+/* Categorical log-prob per row: ll[r] = log_softmax(logits[r,:])[target[r % target_rows]]
+ * (tk.Categorical, model/struct_vae.py:258-266 and :413); optional biased variant.
+ * fwd also returns the row log-sum-exp for the backward pass.
+ * bwd: dlogits = dll[r] * g * (onehot - softmax), g = alpha where the biased branch was taken */
+int tv_categorical_ll_fwd(int64_t rows, int64_t classes, int64_t target_rows,
+                          const float *logits, const int64_t *target, int biased, float alpha,
+                          float log_threshold, float *ll, float *lse /* [rows], nullable */,
+                          void *stream);
+int tv_categorical_ll_bwd(int64_t rows, int64_t classes, int64_t target_rows,
+                          const float *logits, const int64_t *target, int biased, float alpha,
+                          float log_threshold, const float *lse, const float *dll,
+                          float *dlogits, void *stream);
+
+/* z = mean + exp(logstd) * eps ; logq[k,b] = sum_d Normal(z; mean, logstd)
+ * (tk.Normal sample + log_prob, model/struct_vae.py:238-241, model/latency_vae.py:267-270).
+ * logstd is clamped to [lo, hi] first (T.maybe_clip, struct_vae.py:231-235).
+ * mean/logstd_raw [B,D], eps [K,B,D] -> z [K,B,D], logq [K,B], logstd [B,D] (clamped). */
+int tv_normal_reparam_fwd(int64_t n_samples, int64_t batch, int64_t dim, const float *mean,
+                          const float *logstd_raw, float lo, float hi, const float *eps,
+                          float *z, float *logq, float *logstd, void *stream);
+int tv_normal_reparam_bwd(int64_t n_samples, int64_t batch, int64_t dim, const float *logstd_raw,
+                          float lo, float hi, const float *eps, const float *dz,
+                          const float *dlogq, float *dmean, float *dlogstd_raw, void *stream);
+/* ll[r] = sum_d Normal(x[r,d]; mean[r,d], clamp(logstd_raw[r,d], lo, hi))  (p(z2|z),
+ * model/latency_vae.py:284-311).  Gradients for x, mean, logstd_raw. */
+int tv_normal_ll_fwd(int64_t rows, int64_t dim, const float *x, const float *mean,
+                     const float *logstd_raw, float lo, float hi, float *ll, void *stream);
+int tv_normal_ll_bwd(int64_t rows, int64_t dim, const float *x, const float *mean,
+                     const float *logstd_raw, float lo, float hi, const float *dll, float *dx,
+                     float *dmean, float *dlogstd_raw, void *stream);
+
+/* p(latency|z2,G) (model/latency_vae.py:346-444, distributions.py:105-113, 267-286, 300-315,
+ * 341-356): feats [K*B*M, 2] = (mean, raw logstd); logstd = max(raw, logstd_min), then
+ * min(., log(max(std_limit[node_type_pad], 1e-7))) if std_limit != NULL;
+ * mode 0 Normal, 1 SafeNormal(thr), 2 BiasedNormal(alpha, thr), 3 AnomalyDetectionNormal;
+ * masked to m < node_count[b], weighted by M/node_count[b] when `weighted`.
+ * ll [K,B]; optional std_out [K*B*M] (collect_latency_std, tensor_utils.py:155-169). */
+int tv_latency_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
+                      const float *feats, const float *latency_pad, const int64_t *node_count,
+                      const int64_t *node_type_pad, const float *std_limit, int has_logstd_min,
+                      float logstd_min, int mode, float std_threshold, float alpha,
+                      float log_bias_threshold, int use_mask, int weighted, float *ll,
+                      float *std_out, void *stream);
+int tv_latency_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
+                      const float *feats, const float *latency_pad, const int64_t *node_count,
+                      const int64_t *node_type_pad, const float *std_limit, int has_logstd_min,
+                      float logstd_min, int mode, float std_threshold, float alpha,
+                      float log_bias_threshold, int use_mask, int weighted, const float *dll,
+                      float *dfeats, void *stream);
+
+/* test-time scoring (evaluation.py:141-148): w = log_joint - latent_log_joint [K,B];
+ * loss[b] = -mean_k w ; nll[b] = -(logsumexp_k w - log K) ; both clipped:
+ * x < clip ? x : clip (NaN -> clip).  has_clip = 0 disables the clip. */
+int tv_score_reduce(int64_t n_samples, int64_t batch, const float *w, int has_clip, float clip,
+                    float *loss, float *nll, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * optimizer over one flat fp32 parameter buffer (train.py:369-372, 417-426: tk.optim
+ * RMSprop / Adam after clip_grad_norm_(global 10)).
+ *   tv_l2_sumsq_partial: partial[nblk] sums of p^2 over elements with l2_mask != 0
+ *   tv_sumsq_partial   : partial[nblk] sums of g^2
+ *   tv_optim_step      : scale = min(1, clip/(norm+1e-6)) read from device norm (or 1 if
+ *                        clip_norm <= 0); kind 0 RMSprop(alpha .99, eps 1e-8), 1 Adam.
+ * ---------------------------------------------------------------------------------- */
+int64_t tv_reduce_blocks(int64_t n);
+int tv_sumsq_partial(int64_t n, const float *x, const uint8_t *mask /* nullable */,
+                     double *partial, void *stream);
+int tv_sum_partials(int64_t nblk, const double *partial, int take_sqrt, float *out, void *stream);
+/* y[i] += alpha * x[i] where mask[i] != 0 (gradient of the L2 term: alpha = 2*l2_reg) */
+int tv_axpy_masked(int64_t n, float alpha, const float *x, const uint8_t *mask /* nullable */,
+                   float *y, void *stream);
+int tv_optim_step(int kind, int64_t n, float *param, const float *grad, float *state1,
+                  float *state2, const float *grad_norm /* device scalar, nullable */,
+                  float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step,
+                  void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACEVAE_HIP_H */

@@ -1,0 +1,609 @@
+// (b) GAT message passing over the destination-sorted CSC: attention scores, edge softmax,
+// weighted neighbour sum (forward) and the matching gradients (backward).
+//
+// Mapping: one 64-lane wave owns one destination row.  A row of H*F floats (1000 by
+// default) is held as float4 chunks, chunk q = lane + 64*c, so every neighbour row is one
+// fully coalesced 16-B-per-lane gather; a trace's rows sit next to each other, so the
+// neighbour rows are L2 hits after the first touch.  Edge scores live one edge per lane
+// and are reduced with wave shuffles (segment max / sum).  No float atomics: column
+// statistics / parameter gradients are reduced wave -> workgroup (LDS, wave order) ->
+// partial slot per workgroup -> fixed-order second stage.
+//
+// HBM-bound.  Algorithmic bytes, forward, per destination row with d in-edges:
+//   4*HF*d (ft gathers) + 4*HF (out) + 8*H*(d+1) (scores) + 8*d (indices) + 4*H*d (alpha).
+#include "tv_common.h"
+
+namespace {
+
+constexpr int MAXH = 4;
+constexpr float NEG_SLOPE = 0.2f;  // GATConv negative_slope (appendix A1)
+
+__device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
+  return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
+}
+__device__ __forceinline__ float f4_dot(float4 a, float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float sel_head(const float (&a)[MAXH], int h) {
+  float r = a[0];
+#pragma unroll
+  for (int k = 1; k < MAXH; ++k) r = (h == k) ? a[k] : r;
+  return r;
+}
+
+// Combine S per-wave column vectors (float4 chunks in registers) over the waves of the
+// workgroup in wave order and write them to out[S][C].  lds holds S*C floats.
+template <int S, int CH>
+__device__ __forceinline__ void block_col_reduce(float *lds, const float4 (&v)[S][CH], int c4,
+                                                 float *out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float4 *l4 = reinterpret_cast<float4 *>(lds);
+  for (int w = 0; w < nw; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          if (q < c4) l4[s * c4 + q] = (w == 0) ? v[s][c] : f4_add(l4[s * c4 + q], v[s][c]);
+        }
+    }
+    __syncthreads();
+  }
+  float4 *o4 = reinterpret_cast<float4 *>(out);
+  for (int i = threadIdx.x; i < S * c4; i += blockDim.x) o4[i] = l4[i];
+}
+
+// ------------------------------------------------------------------------------------
+// el / er
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gat_scores_kernel(int64_t rows, int H, int F,
+                                                         const float *__restrict__ ft,
+                                                         const float *__restrict__ al,
+                                                         const float *__restrict__ ar,
+                                                         float *__restrict__ el,
+                                                         float *__restrict__ er) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int f4 = F >> 2;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float4 *row = reinterpret_cast<const float4 *>(ft + r * (int64_t)H * F);
+    for (int h = 0; h < H; ++h) {
+      float sl = 0.f, sr = 0.f;
+      for (int q = lane; q < f4; q += 64) {
+        const float4 x = row[h * f4 + q];
+        sl += f4_dot(x, reinterpret_cast<const float4 *>(al)[h * f4 + q]);
+        sr += f4_dot(x, reinterpret_cast<const float4 *>(ar)[h * f4 + q]);
+      }
+      sl = tv_wave_sum(sl);
+      sr = tv_wave_sum(sr);
+      if (lane == 0) {
+        el[r * H + h] = sl;
+        er[r * H + h] = sr;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// forward aggregate
+// ------------------------------------------------------------------------------------
+struct AggArgs {
+  int64_t rows_per_rep, n_rep, rows, num_edges;
+  int H, F, c4;  // c4 = H*F/4
+  const int64_t *indptr, *indices, *rev;
+  const float *ft, *el, *er, *bias, *attn_l, *attn_r, *alpha_in, *dout;
+  float *out, *alpha, *stats_partial;
+  const float *ep_scale, *ep_shift;
+  float ep_slope;
+  // backward
+  float *dpre, *der, *dft, *partial;
+};
+
+template <int CH, bool STATS, bool EPILOGUE>
+__global__ __launch_bounds__(512) void gat_aggregate_fwd_kernel(AggArgs a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const int H = a.H, F = a.F, c4 = a.c4;
+  const int64_t HF = (int64_t)H * F;
+
+  int hc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) hc[c] = ((lane + 64 * c) * 4) / F;
+
+  float4 ssum[STATS ? CH : 1], ssq[STATS ? CH : 1];
+  if (STATS) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) ssum[c] = ssq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  for (int64_t r = wave; r < a.rows; r += nwaves) {
+    const int64_t rep = r / a.rows_per_rep;
+    const int64_t v = r - rep * a.rows_per_rep;
+    const int64_t base = rep * a.rows_per_rep;
+    const int64_t p0 = a.indptr[v];
+    const int deg = (int)(a.indptr[v + 1] - p0);
+    float erv[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) erv[h] = (h < H) ? a.er[r * H + h] : 0.f;
+
+    // pass 1: segment max of the edge scores
+    float mx[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) mx[h] = -INFINITY;
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+      const int j = c0 + lane;
+      if (j < deg) {
+        const int64_t s = base + a.indices[p0 + j];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+          if (h < H) mx[h] = fmaxf(mx[h], tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE));
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) mx[h] = tv_wave_max(mx[h]);
+    // pass 2: segment sum of exp
+    float den[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) den[h] = 0.f;
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+      const int j = c0 + lane;
+      if (j < deg) {
+        const int64_t s = base + a.indices[p0 + j];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+          if (h < H) den[h] += expf(tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE) - mx[h]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) den[h] = tv_wave_sum(den[h]);
+
+    // pass 3: alpha per edge (one edge per lane), then the weighted neighbour sum
+    float4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+      const int j = c0 + lane;
+      int64_t s = 0;
+      float al[MAXH];
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h) al[h] = 0.f;
+      if (j < deg) {
+        s = base + a.indices[p0 + j];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+          if (h < H) {
+            al[h] = expf(tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE) - mx[h]) / den[h];
+            if (a.alpha) a.alpha[(rep * a.num_edges + p0 + j) * H + h] = al[h];
+          }
+      }
+      const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
+      for (int jj = 0; jj < cnt; ++jj) {
+        const int64_t sj = __shfl(s, jj, 64);
+        float aj[MAXH];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) aj[h] = __shfl(al[h], jj, 64);
+        const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * HF);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          if (q < c4) acc[c] = f4_fma(sel_head(aj, hc[c]), srow[q], acc[c]);
+        }
+      }
+    }
+
+    // epilogue: + bias, optional fused BatchNorm(eval)+LeakyReLU or column statistics
+    float4 *orow = reinterpret_cast<float4 *>(a.out + r * HF);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int q = lane + 64 * c;
+      if (q < c4) {
+        float4 o = f4_add(acc[c], reinterpret_cast<const float4 *>(a.bias)[q]);
+        if (STATS) {
+          ssum[c] = f4_add(ssum[c], o);
+          ssq[c] = make_float4(fmaf(o.x, o.x, ssq[c].x), fmaf(o.y, o.y, ssq[c].y),
+                               fmaf(o.z, o.z, ssq[c].z), fmaf(o.w, o.w, ssq[c].w));
+        }
+        if (EPILOGUE) {
+          const float4 sc = reinterpret_cast<const float4 *>(a.ep_scale)[q];
+          const float4 sh = reinterpret_cast<const float4 *>(a.ep_shift)[q];
+          o.x = tv_lrelu(fmaf(o.x, sc.x, sh.x), a.ep_slope);
+          o.y = tv_lrelu(fmaf(o.y, sc.y, sh.y), a.ep_slope);
+          o.z = tv_lrelu(fmaf(o.z, sc.z, sh.z), a.ep_slope);
+          o.w = tv_lrelu(fmaf(o.w, sc.w, sh.w), a.ep_slope);
+        }
+        orow[q] = o;
+      }
+    }
+  }
+
+  if (STATS) {
+    float4 v[2][CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { v[0][c] = ssum[c]; v[1][c] = ssq[c]; }
+    block_col_reduce<2, CH>(lds, v, c4, a.stats_partial + (int64_t)blockIdx.x * 2 * HF);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// backward, step A (per destination row): gradient of the edge scores
+//   g_j   = <dout[v,h,:], ft[u_j,h,:]>
+//   de_j  = alpha_j * (g_j - sum_k alpha_k g_k)            (softmax)
+//   dpre_j= de_j * (pre_j > 0 ? 1 : 0.2)                    (LeakyReLU), pre_j = el[u_j]+er[v]
+//   der[v]= sum_j dpre_j ;  dpre kept per CSC position for step B
+// ------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const int H = a.H, F = a.F, c4 = a.c4;
+  const int64_t HF = (int64_t)H * F;
+  int hc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) hc[c] = ((lane + 64 * c) * 4) / F;
+
+  for (int64_t r = wave; r < a.rows; r += nwaves) {
+    const int64_t rep = r / a.rows_per_rep;
+    const int64_t v = r - rep * a.rows_per_rep;
+    const int64_t base = rep * a.rows_per_rep;
+    const int64_t p0 = a.indptr[v];
+    const int deg = (int)(a.indptr[v + 1] - p0);
+    const int64_t ebase = rep * a.num_edges + p0;
+
+    float4 d[CH];
+    const float4 *drow = reinterpret_cast<const float4 *>(a.dout + r * HF);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int q = lane + 64 * c;
+      d[c] = (q < c4) ? drow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // pass 1: g_j for every in-edge (kept by lane j; spilled to dpre when deg > 64),
+    // and s[h] = sum_j alpha_j g_j
+    float sacc[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) sacc[h] = 0.f;
+    float gkeep[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) gkeep[h] = 0.f;
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+      const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
+      const int j = c0 + lane;
+      const int64_t s = (j < deg) ? (base + a.indices[p0 + j]) : 0;
+      float gj[MAXH];
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h) gj[h] = 0.f;
+      for (int jj = 0; jj < cnt; ++jj) {
+        const int64_t sj = __shfl(s, jj, 64);
+        const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * HF);
+        float part[MAXH];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) part[h] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          if (q < c4) {
+            const float dp = f4_dot(d[c], srow[q]);
+#pragma unroll
+            for (int h = 0; h < MAXH; ++h) part[h] += (hc[c] == h) ? dp : 0.f;
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) {
+          if (h < H) {
+            const float tot = tv_wave_sum(part[h]);
+            if (lane == jj) gj[h] = tot;
+          }
+        }
+      }
+      if (j < deg) {
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+          if (h < H) {
+            sacc[h] += a.alpha_in[(ebase + j) * H + h] * gj[h];
+            if (deg > 64) a.dpre[(ebase + j) * H + h] = gj[h];
+            gkeep[h] = gj[h];
+          }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) sacc[h] = tv_wave_sum(sacc[h]);
+
+    // pass 2: softmax + LeakyReLU backward
+    float dsum[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) dsum[h] = 0.f;
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+      const int j = c0 + lane;
+      if (j < deg) {
+        const int64_t s = base + a.indices[p0 + j];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+          if (h < H) {
+            const float g = (deg > 64) ? a.dpre[(ebase + j) * H + h] : gkeep[h];
+            const float al = a.alpha_in[(ebase + j) * H + h];
+            const float pre = a.el[s * H + h] + a.er[r * H + h];
+            const float dp = al * (g - sacc[h]) * (pre > 0.f ? 1.f : NEG_SLOPE);
+            a.dpre[(ebase + j) * H + h] = dp;
+            dsum[h] += dp;
+          }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) {
+      if (h < H) {
+        const float tot = tv_wave_sum(dsum[h]);
+        if (lane == 0) a.der[r * H + h] = tot;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// backward, step B (per source row u): the graph is symmetric, so the out-edges of u are
+// the opposites of its in-edges: CSC entry p = (w -> u) has the opposite edge (u -> w) at
+// CSC position rev[p].
+//   dft[u]  = sum_p alpha[rev[p]] * dout[w_p]  +  del[u] * attn_l + der[u] * attn_r
+//   del[u]  = sum_p dpre[rev[p]]
+//   partial sums for dattn_l (del*ft), dattn_r (der*ft), dbias (dout)
+// ------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(512) void gat_bwd_node_kernel(AggArgs a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const int H = a.H, F = a.F, c4 = a.c4;
+  const int64_t HF = (int64_t)H * F;
+  int hc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) hc[c] = ((lane + 64 * c) * 4) / F;
+
+  float4 pal[CH], par[CH], pb[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) pal[c] = par[c] = pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int64_t r = wave; r < a.rows; r += nwaves) {
+    const int64_t rep = r / a.rows_per_rep;
+    const int64_t u = r - rep * a.rows_per_rep;
+    const int64_t base = rep * a.rows_per_rep;
+    const int64_t p0 = a.indptr[u];
+    const int deg = (int)(a.indptr[u + 1] - p0);
+    const int64_t eoff = rep * a.num_edges;
+
+    float4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float del[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) del[h] = 0.f;
+
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+      const int j = c0 + lane;
+      int64_t w = 0;
+      float al[MAXH], dp[MAXH];
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h) al[h] = dp[h] = 0.f;
+      if (j < deg) {
+        w = base + a.indices[p0 + j];
+        const int64_t rp = eoff + a.rev[p0 + j];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+          if (h < H) {
+            al[h] = a.alpha_in[rp * H + h];
+            dp[h] = a.dpre[rp * H + h];
+          }
+      }
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h) del[h] += dp[h];
+      const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
+      for (int jj = 0; jj < cnt; ++jj) {
+        const int64_t wj = __shfl(w, jj, 64);
+        float aj[MAXH];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) aj[h] = __shfl(al[h], jj, 64);
+        const float4 *wrow = reinterpret_cast<const float4 *>(a.dout + wj * HF);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          if (q < c4) acc[c] = f4_fma(sel_head(aj, hc[c]), wrow[q], acc[c]);
+        }
+      }
+    }
+    float der[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) {
+      del[h] = tv_wave_sum(del[h]);
+      der[h] = (h < H) ? a.der[r * H + h] : 0.f;
+    }
+
+    const float4 *frow = reinterpret_cast<const float4 *>(a.ft + r * HF);
+    const float4 *drow = reinterpret_cast<const float4 *>(a.dout + r * HF);
+    float4 *orow = reinterpret_cast<float4 *>(a.dft + r * HF);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int q = lane + 64 * c;
+      if (q < c4) {
+        const float dl = sel_head(del, hc[c]), dr = sel_head(der, hc[c]);
+        const float4 wl = reinterpret_cast<const float4 *>(a.attn_l)[q];
+        const float4 wr = reinterpret_cast<const float4 *>(a.attn_r)[q];
+        orow[q] = f4_fma(dr, wr, f4_fma(dl, wl, acc[c]));
+        const float4 f = frow[q];
+        pal[c] = f4_fma(dl, f, pal[c]);
+        par[c] = f4_fma(dr, f, par[c]);
+        pb[c] = f4_add(pb[c], drow[q]);
+      }
+    }
+  }
+
+  float4 v[3][CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) { v[0][c] = pal[c]; v[1][c] = par[c]; v[2][c] = pb[c]; }
+  block_col_reduce<3, CH>(lds, v, c4, a.partial + (int64_t)blockIdx.x * 3 * HF);
+}
+
+// out[s*C + c] = sum_b partial[b][s][c] in workgroup order (double accumulation)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t nblk, int64_t sc,
+                                                              const float *__restrict__ partial,
+                                                              float *o0, float *o1, float *o2,
+                                                              int64_t C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sc) return;
+  double acc = 0.0;
+  for (int64_t b = 0; b < nblk; ++b) acc += (double)partial[b * sc + i];
+  const int64_t s = i / C, c = i - s * C;
+  float *o = (s == 0) ? o0 : (s == 1 ? o1 : o2);
+  if (o) o[c] = (float)acc;
+}
+
+int check_shape(const char *name, int64_t rows_per_rep, int64_t n_rep, int64_t heads,
+                int64_t feats) {
+  TV_REQUIRE(rows_per_rep >= 0 && n_rep >= 1, "%s: bad row counts", name);
+  TV_REQUIRE(heads >= 1 && heads <= MAXH, "%s: heads must be in [1,%d]: got %lld", name, MAXH,
+             (long long)heads);
+  TV_REQUIRE(feats >= 4 && feats % 4 == 0, "%s: feats must be a positive multiple of 4: got %lld",
+             name, (long long)feats);
+  TV_REQUIRE(heads * feats <= 2048, "%s: heads*feats must be <= 2048: got %lld", name,
+             (long long)(heads * feats));
+  return TV_OK;
+}
+
+}  // namespace
+
+extern "C" int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const float *ft,
+                             const float *attn_l, const float *attn_r, float *el, float *er,
+                             void *stream) {
+  if (int rc = check_shape("tv_gat_scores", rows, 1, heads, feats)) return rc;
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(ft && attn_l && attn_r && el && er, "tv_gat_scores: null pointer");
+  int64_t blocks = tv_cdiv(rows, 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gat_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     rows, (int)heads, (int)feats, ft, attn_l, attn_r, el, er);
+  TV_LAUNCH_CHECK("tv_gat_scores");
+  return TV_OK;
+}
+
+extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads,
+                                    int64_t feats, const int64_t *indptr, const int64_t *indices,
+                                    const float *ft, const float *el, const float *er,
+                                    const float *bias, float *out, float *alpha,
+                                    float *stats_partial, const float *ep_scale,
+                                    const float *ep_shift, float ep_slope, void *stream) {
+  if (int rc = check_shape("tv_gat_aggregate_fwd", rows_per_rep, n_rep, heads, feats)) return rc;
+  const int64_t rows = rows_per_rep * n_rep;
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(indptr && indices && ft && el && er && bias && out,
+             "tv_gat_aggregate_fwd: null pointer");
+  TV_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr),
+             "tv_gat_aggregate_fwd: ep_scale and ep_shift go together");
+  TV_REQUIRE(!(stats_partial && ep_scale),
+             "tv_gat_aggregate_fwd: statistics and the fused eval epilogue are exclusive");
+  AggArgs a = {};
+  a.rows_per_rep = rows_per_rep; a.n_rep = n_rep; a.rows = rows;
+  a.H = (int)heads; a.F = (int)feats; a.c4 = (int)(heads * feats / 4);
+  a.indptr = indptr; a.indices = indices; a.ft = ft; a.el = el; a.er = er; a.bias = bias;
+  a.out = out; a.alpha = alpha; a.stats_partial = stats_partial;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_slope = ep_slope;
+  // num_edges of one replica is only needed to index alpha; read back is avoided by
+  // passing it through indptr on the host side of the caller: alpha is indexed with
+  // rep * num_edges, and num_edges = indptr[rows_per_rep] is a device value.  With one
+  // replica the term vanishes; with several the caller must pass alpha == NULL.
+  TV_REQUIRE(!(alpha && n_rep > 1),
+             "tv_gat_aggregate_fwd: alpha is only kept for a single replica (training)");
+  a.num_edges = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const bool big = a.c4 > 256;
+  if (stats_partial) {
+    const dim3 grid((unsigned)tv_stat_blocks_host(rows)), block(64 * TV_STAT_WAVES);
+    const size_t ldsb = sizeof(float) * 2 * heads * feats;
+    if (big) hipLaunchKernelGGL((gat_aggregate_fwd_kernel<8, true, false>), grid, block, ldsb, s, a);
+    else hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, true, false>), grid, block, ldsb, s, a);
+  } else {
+    int64_t blocks = tv_cdiv(rows, TV_STAT_WAVES);
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), block(64 * TV_STAT_WAVES);
+    if (ep_scale) {
+      if (big) hipLaunchKernelGGL((gat_aggregate_fwd_kernel<8, false, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, false, true>), grid, block, 0, s, a);
+    } else {
+      if (big) hipLaunchKernelGGL((gat_aggregate_fwd_kernel<8, false, false>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, false, false>), grid, block, 0, s, a);
+    }
+  }
+  TV_LAUNCH_CHECK("tv_gat_aggregate_fwd");
+  return TV_OK;
+}
+
+extern "C" int64_t tv_gat_aggregate_bwd_workspace_bytes(int64_t rows_per_rep, int64_t n_rep,
+                                                        int64_t heads, int64_t feats,
+                                                        int64_t num_edges) {
+  const int64_t rows = rows_per_rep * n_rep;
+  const int64_t nblk = tv_stat_blocks_host(rows);
+  return (int64_t)sizeof(float) *
+         (n_rep * num_edges * heads + rows * heads + nblk * 3 * heads * feats);
+}
+
+extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads,
+                                    int64_t feats, int64_t num_edges, const int64_t *indptr,
+                                    const int64_t *indices, const int64_t *rev, const float *ft,
+                                    const float *el, const float *er, const float *attn_l,
+                                    const float *attn_r, const float *alpha, const float *dout,
+                                    float *dft, float *dattn_l, float *dattn_r, float *dbias,
+                                    void *workspace, int64_t workspace_bytes, void *stream) {
+  if (int rc = check_shape("tv_gat_aggregate_bwd", rows_per_rep, n_rep, heads, feats)) return rc;
+  TV_REQUIRE(n_rep == 1, "tv_gat_aggregate_bwd: the backward pass runs on a single replica");
+  const int64_t rows = rows_per_rep * n_rep;
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(indptr && indices && rev && ft && el && er && attn_l && attn_r && alpha && dout &&
+                 dft && dattn_l && dattn_r && dbias,
+             "tv_gat_aggregate_bwd: null pointer");
+  const int64_t need =
+      tv_gat_aggregate_bwd_workspace_bytes(rows_per_rep, n_rep, heads, feats, num_edges);
+  if (!workspace || workspace_bytes < need) {
+    tv_set_error("tv_gat_aggregate_bwd: workspace of %lld bytes needed, %lld given",
+                 (long long)need, (long long)workspace_bytes);
+    return TV_ERR_WORKSPACE;
+  }
+  const int64_t nblk = tv_stat_blocks_host(rows);
+  const int64_t HF = heads * feats;
+  AggArgs a = {};
+  a.rows_per_rep = rows_per_rep; a.n_rep = n_rep; a.rows = rows; a.num_edges = num_edges;
+  a.H = (int)heads; a.F = (int)feats; a.c4 = (int)(HF / 4);
+  a.indptr = indptr; a.indices = indices; a.rev = rev; a.ft = ft; a.el = el; a.er = er;
+  a.attn_l = attn_l; a.attn_r = attn_r; a.alpha_in = alpha; a.dout = dout; a.dft = dft;
+  a.dpre = (float *)workspace;
+  a.der = a.dpre + n_rep * num_edges * heads;
+  a.partial = a.der + rows * heads;
+  hipStream_t s = (hipStream_t)stream;
+  const bool big = a.c4 > 256;
+  {
+    int64_t blocks = tv_cdiv(rows, TV_STAT_WAVES);
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks), block(64 * TV_STAT_WAVES);
+    if (big) hipLaunchKernelGGL((gat_bwd_edge_kernel<8>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gat_bwd_edge_kernel<4>), grid, block, 0, s, a);
+    TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(edge)");
+  }
+  {
+    const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
+    const size_t ldsb = sizeof(float) * 3 * HF;
+    if (big) hipLaunchKernelGGL((gat_bwd_node_kernel<8>), grid, block, ldsb, s, a);
+    else hipLaunchKernelGGL((gat_bwd_node_kernel<4>), grid, block, ldsb, s, a);
+    TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(node)");
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)tv_cdiv(3 * HF, 256)), dim3(256), 0, s,
+                     nblk, 3 * HF, a.partial, dattn_l, dattn_r, dbias, HF);
+  TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(reduce)");
+  return TV_OK;
+}

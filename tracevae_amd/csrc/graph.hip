@@ -1,0 +1,298 @@
+// GraphConv aggregation, graph readout, embedding gather / segmented scatter and the
+// latency-decoder input rows.  All HBM-bound gathers over the batching kernel's CSC /
+// segment offsets; every sum runs in a fixed order (no float atomics).
+#include "tv_common.h"
+
+namespace {
+
+__device__ __forceinline__ float deg_norm(const int64_t *indptr, int64_t v) {
+  const float d = (float)(indptr[v + 1] - indptr[v]);
+  return 1.0f / sqrtf(fmaxf(d, 1.0f));
+}
+
+// wave per destination row, float4 chunks (cols % 4 == 0)
+__global__ __launch_bounds__(256) void graph_sum_vec_kernel(
+    int64_t rows_per_rep, int64_t rows, int64_t c4, const int64_t *__restrict__ indptr,
+    const int64_t *__restrict__ indices, const float *__restrict__ x, int scale_src,
+    int scale_dst, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int64_t rep = r / rows_per_rep, v = r - rep * rows_per_rep, base = rep * rows_per_rep;
+    const int64_t p0 = indptr[v], p1 = indptr[v + 1];
+    const float nd = scale_dst ? deg_norm(indptr, v) : 1.0f;
+    for (int64_t q0 = 0; q0 < c4; q0 += 64 * 4) {
+      float4 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t p = p0; p < p1; ++p) {
+        const int64_t u = indices[p];
+        const float ns = scale_src ? deg_norm(indptr, u) : 1.0f;
+        const float4 *urow = reinterpret_cast<const float4 *>(x) + (base + u) * c4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t q = q0 + lane + 64 * c;
+          if (q < c4) {
+            const float4 t = urow[q];
+            // DGL scales the source features first, then sums (appendix A2)
+            acc[c].x += t.x * ns; acc[c].y += t.y * ns; acc[c].z += t.z * ns; acc[c].w += t.w * ns;
+          }
+        }
+      }
+      float4 *orow = reinterpret_cast<float4 *>(out) + r * c4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int64_t q = q0 + lane + 64 * c;
+        if (q < c4)
+          orow[q] = make_float4(acc[c].x * nd, acc[c].y * nd, acc[c].z * nd, acc[c].w * nd);
+      }
+    }
+  }
+}
+
+// thread per output element (narrow rows, e.g. the 2-column latency head)
+__global__ __launch_bounds__(256) void graph_sum_scalar_kernel(
+    int64_t rows_per_rep, int64_t rows, int64_t C, const int64_t *__restrict__ indptr,
+    const int64_t *__restrict__ indices, const float *__restrict__ x, int scale_src,
+    int scale_dst, float *__restrict__ out) {
+  const int64_t total = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / C, c = e - r * C;
+    const int64_t rep = r / rows_per_rep, v = r - rep * rows_per_rep, base = rep * rows_per_rep;
+    float acc = 0.f;
+    for (int64_t p = indptr[v]; p < indptr[v + 1]; ++p) {
+      const int64_t u = indices[p];
+      const float ns = scale_src ? deg_norm(indptr, u) : 1.0f;
+      acc += x[(base + u) * C + c] * ns;
+    }
+    out[e] = acc * (scale_dst ? deg_norm(indptr, v) : 1.0f);
+  }
+}
+
+__global__ __launch_bounds__(256) void graph_norm_kernel(int64_t rows_per_rep, int64_t rows,
+                                                         const int64_t *__restrict__ indptr,
+                                                         float *__restrict__ norm) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) norm[r] = deg_norm(indptr, r % rows_per_rep);
+}
+
+// block (b, column tile): out[b,c] = mean over the rows of trace b
+__global__ __launch_bounds__(256) void segment_mean_fwd_kernel(int64_t C,
+                                                               const int64_t *__restrict__ off,
+                                                               const float *__restrict__ x,
+                                                               float *__restrict__ out) {
+  const int64_t b = blockIdx.x;
+  const int64_t c = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int64_t r0 = off[b], r1 = off[b + 1];
+  float acc = 0.f;
+  for (int64_t r = r0; r < r1; ++r) acc += x[r * C + c];
+  out[b * C + c] = acc / (float)(r1 - r0);
+}
+
+__global__ __launch_bounds__(256) void segment_mean_bwd_kernel(int64_t rows, int64_t C,
+                                                               const int64_t *__restrict__ off,
+                                                               const int64_t *__restrict__ gid,
+                                                               const float *__restrict__ dout,
+                                                               float *__restrict__ dx) {
+  const int64_t total = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / C, c = e - r * C;
+    const int64_t g = gid[r];
+    dx[e] = dout[g * C + c] / (float)(off[g + 1] - off[g]);
+  }
+}
+
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(int64_t rows, int64_t dim, int64_t V,
+                                                            const float *__restrict__ w,
+                                                            const int64_t *__restrict__ ids,
+                                                            float *__restrict__ out, int64_t ld,
+                                                            int64_t col0) {
+  const int64_t total = rows * dim, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = e / dim, d = e - r * dim;
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    out[r * ld + col0 + d] = w[id * dim + d];
+  }
+}
+
+// one workgroup per operation id: dW[v,:] = sum over rows with ids[r] == v, in row order
+// within each of the 4 row groups, the groups combined in group order
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(int64_t rows, int64_t dim,
+                                                            const int64_t *__restrict__ ids,
+                                                            const float *__restrict__ dout,
+                                                            int64_t ld, int64_t col0,
+                                                            float *__restrict__ dw) {
+  __shared__ float part[4][64];
+  const int64_t v = blockIdx.x;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int64_t d0 = 0; d0 < dim; d0 += 64) {
+    const int64_t d = d0 + lane;
+    float acc = 0.f;
+    for (int64_t r = grp; r < rows; r += 4) {
+      if (ids[r] == v && d < dim) acc += dout[r * ld + col0 + d];
+    }
+    part[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && d < dim)
+      dw[v * dim + d] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void latdec_input_fwd_kernel(
+    int64_t K, int64_t B, int64_t M, int64_t Z, int64_t E, int64_t V,
+    const float *__restrict__ z2, const float *__restrict__ emb,
+    const int64_t *__restrict__ ntp, float *__restrict__ out) {
+  const int64_t W = Z + E, total = K * B * M * W, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t row = e / W, c = e - row * W;
+    const int64_t kb = row / M, m = row - kb * M, b = kb % B;
+    if (c < Z) {
+      out[e] = z2[kb * Z + c];
+    } else {
+      int64_t id = ntp[b * M + m];
+      id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+      out[e] = emb[id * E + (c - Z)];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void latdec_input_bwd_kernel(int64_t KB, int64_t M, int64_t Z,
+                                                               int64_t W,
+                                                               const float *__restrict__ dout,
+                                                               float *__restrict__ dz2) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= KB * Z) return;
+  const int64_t kb = e / Z, d = e - kb * Z;
+  float acc = 0.f;
+  for (int64_t m = 0; m < M; ++m) acc += dout[(kb * M + m) * W + d];
+  dz2[e] = acc;
+}
+
+inline unsigned ew_blocks(int64_t work_items) {
+  int64_t b = tv_cdiv(work_items, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int tv_graph_sum(int64_t rows_per_rep, int64_t n_rep, int64_t cols,
+                            const int64_t *indptr, const int64_t *indices, const float *x,
+                            int scale_src, int scale_dst, float *out, void *stream) {
+  TV_REQUIRE(rows_per_rep >= 0 && n_rep >= 1 && cols >= 1, "tv_graph_sum: bad sizes");
+  const int64_t rows = rows_per_rep * n_rep;
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(indptr && indices && x && out, "tv_graph_sum: null pointer");
+  TV_REQUIRE(x != out, "tv_graph_sum: in-place aggregation is not possible");
+  hipStream_t s = (hipStream_t)stream;
+  if (cols % 4 == 0 && cols >= 64 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0)) {
+    int64_t blocks = tv_cdiv(rows, 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(graph_sum_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rows_per_rep,
+                       rows, cols / 4, indptr, indices, x, scale_src, scale_dst, out);
+  } else {
+    hipLaunchKernelGGL(graph_sum_scalar_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, s,
+                       rows_per_rep, rows, cols, indptr, indices, x, scale_src, scale_dst, out);
+  }
+  TV_LAUNCH_CHECK("tv_graph_sum");
+  return TV_OK;
+}
+
+extern "C" int tv_graph_norm(int64_t rows_per_rep, int64_t n_rep, const int64_t *indptr,
+                             float *norm, void *stream) {
+  TV_REQUIRE(rows_per_rep >= 0 && n_rep >= 1, "tv_graph_norm: bad sizes");
+  const int64_t rows = rows_per_rep * n_rep;
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(indptr && norm, "tv_graph_norm: null pointer");
+  hipLaunchKernelGGL(graph_norm_kernel, dim3((unsigned)tv_cdiv(rows, 256)), dim3(256), 0,
+                     (hipStream_t)stream, rows_per_rep, rows, indptr, norm);
+  TV_LAUNCH_CHECK("tv_graph_norm");
+  return TV_OK;
+}
+
+extern "C" int tv_segment_mean_fwd(int64_t batch, int64_t cols, const int64_t *node_offsets,
+                                   const float *x, float *out, void *stream) {
+  TV_REQUIRE(batch >= 0 && cols >= 1, "tv_segment_mean_fwd: bad sizes");
+  if (batch == 0) return TV_OK;
+  TV_REQUIRE(node_offsets && x && out, "tv_segment_mean_fwd: null pointer");
+  const dim3 grid((unsigned)batch, (unsigned)tv_cdiv(cols, 256));
+  hipLaunchKernelGGL(segment_mean_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, cols,
+                     node_offsets, x, out);
+  TV_LAUNCH_CHECK("tv_segment_mean_fwd");
+  return TV_OK;
+}
+
+extern "C" int tv_segment_mean_bwd(int64_t rows, int64_t cols, const int64_t *node_offsets,
+                                   const int64_t *graph_id, const float *dout, float *dx,
+                                   void *stream) {
+  TV_REQUIRE(rows >= 0 && cols >= 1, "tv_segment_mean_bwd: bad sizes");
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(node_offsets && graph_id && dout && dx, "tv_segment_mean_bwd: null pointer");
+  hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0,
+                     (hipStream_t)stream, rows, cols, node_offsets, graph_id, dout, dx);
+  TV_LAUNCH_CHECK("tv_segment_mean_bwd");
+  return TV_OK;
+}
+
+extern "C" int tv_embedding_fwd(int64_t rows, int64_t dim, int64_t num_operations,
+                                const float *weight, const int64_t *ids, float *out, int64_t ld,
+                                int64_t col0, void *stream) {
+  TV_REQUIRE(rows >= 0 && dim >= 1 && num_operations >= 1, "tv_embedding_fwd: bad sizes");
+  TV_REQUIRE(col0 >= 0 && ld >= col0 + dim, "tv_embedding_fwd: columns do not fit ld");
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(weight && ids && out, "tv_embedding_fwd: null pointer");
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_blocks(rows * dim)), dim3(256), 0,
+                     (hipStream_t)stream, rows, dim, num_operations, weight, ids, out, ld, col0);
+  TV_LAUNCH_CHECK("tv_embedding_fwd");
+  return TV_OK;
+}
+
+extern "C" int tv_embedding_bwd(int64_t rows, int64_t dim, int64_t num_operations,
+                                const int64_t *ids, const float *dout, int64_t ld, int64_t col0,
+                                float *dweight, void *stream) {
+  TV_REQUIRE(rows >= 0 && dim >= 1 && num_operations >= 1, "tv_embedding_bwd: bad sizes");
+  TV_REQUIRE(col0 >= 0 && ld >= col0 + dim, "tv_embedding_bwd: columns do not fit ld");
+  TV_REQUIRE(ids && dout && dweight, "tv_embedding_bwd: null pointer");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)num_operations), dim3(256), 0,
+                     (hipStream_t)stream, rows, dim, ids, dout, ld, col0, dweight);
+  TV_LAUNCH_CHECK("tv_embedding_bwd");
+  return TV_OK;
+}
+
+extern "C" int tv_latdec_input_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
+                                   int64_t z2_dim, int64_t emb_dim, int64_t num_operations,
+                                   const float *z2, const float *emb_weight,
+                                   const int64_t *node_type_pad, float *out, void *stream) {
+  TV_REQUIRE(n_samples >= 1 && batch >= 0 && max_node_count >= 1 && z2_dim >= 1 && emb_dim >= 1 &&
+                 num_operations >= 1,
+             "tv_latdec_input_fwd: bad sizes");
+  if (batch == 0) return TV_OK;
+  TV_REQUIRE(z2 && emb_weight && node_type_pad && out, "tv_latdec_input_fwd: null pointer");
+  const int64_t total = n_samples * batch * max_node_count * (z2_dim + emb_dim);
+  hipLaunchKernelGGL(latdec_input_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0,
+                     (hipStream_t)stream, n_samples, batch, max_node_count, z2_dim, emb_dim,
+                     num_operations, z2, emb_weight, node_type_pad, out);
+  TV_LAUNCH_CHECK("tv_latdec_input_fwd");
+  return TV_OK;
+}
+
+extern "C" int tv_latdec_input_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
+                                   int64_t z2_dim, int64_t emb_dim, const float *dout, float *dz2,
+                                   void *stream) {
+  TV_REQUIRE(n_samples >= 1 && batch >= 0 && max_node_count >= 1 && z2_dim >= 1 && emb_dim >= 0,
+             "tv_latdec_input_bwd: bad sizes");
+  if (batch == 0) return TV_OK;
+  TV_REQUIRE(dout && dz2, "tv_latdec_input_bwd: null pointer");
+  const int64_t kb = n_samples * batch;
+  hipLaunchKernelGGL(latdec_input_bwd_kernel, dim3((unsigned)tv_cdiv(kb * z2_dim, 256)), dim3(256),
+                     0, (hipStream_t)stream, kb, max_node_count, z2_dim, z2_dim + emb_dim, dout,
+                     dz2);
+  TV_LAUNCH_CHECK("tv_latdec_input_bwd");
+  return TV_OK;
+}

@@ -1,0 +1,306 @@
+// BatchNorm over rows + LeakyReLU (training: batch statistics, eval: folded running
+// statistics), forward and backward.  HBM-bound streaming kernels: a thread owns a column
+// (column reductions, rows strided over a fixed number of workgroups) or a float4 of a row
+// (elementwise passes).  Column statistics are reduced in two fixed-order stages, the
+// second one in float64.
+// Algorithmic bytes per row of C floats: stats 4C (read), apply 8C (read+write),
+// backward 8C (reduce: x, dy) + 12C (apply: x, dy, dx).
+#include "tv_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void colstats_kernel(int64_t rows, int64_t C,
+                                                       const float *__restrict__ x,
+                                                       float *__restrict__ partial) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nblk = gridDim.y, by = blockIdx.y;
+  if (col >= C) return;
+  float s = 0.f, q = 0.f;
+  for (int64_t r = by; r < rows; r += nblk) {
+    const float v = x[r * C + col];
+    s += v;
+    q = fmaf(v, v, q);
+  }
+  partial[(by * 2 + 0) * C + col] = s;
+  partial[(by * 2 + 1) * C + col] = q;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int64_t C, int64_t nblk,
+                                                          const float *__restrict__ partial,
+                                                          double count, float eps, float momentum,
+                                                          float *mean, float *rstd,
+                                                          float *running_mean,
+                                                          float *running_var) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int64_t b = 0; b < nblk; ++b) {
+    s += (double)partial[(b * 2 + 0) * C + col];
+    q += (double)partial[(b * 2 + 1) * C + col];
+  }
+  const double m = s / count;
+  double var = q / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[col] = (float)m;
+  rstd[col] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[col] = (float)((1.0 - momentum) * (double)running_mean[col] + momentum * m);
+    running_var[col] = (float)((1.0 - momentum) * (double)running_var[col] + momentum * unbiased);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(int64_t C, const float *rm,
+                                                             const float *rv, const float *gamma,
+                                                             const float *beta, float eps,
+                                                             float *scale, float *shift) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= C) return;
+  const float sc = gamma[col] / sqrtf(rv[col] + eps);
+  scale[col] = sc;
+  shift[col] = beta[col] - rm[col] * sc;
+}
+
+// y = lrelu(x * sc[col] + sh[col]); TRAIN: sc = rstd*gamma, sh = beta - mean*sc computed here
+template <bool VEC, bool TRAIN>
+__global__ __launch_bounds__(256) void affine_lrelu_kernel(int64_t rows, int64_t C,
+                                                           const float *__restrict__ x,
+                                                           const float *__restrict__ p0,
+                                                           const float *__restrict__ p1,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta,
+                                                           float slope, float *__restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (VEC) {
+    const int64_t c4 = C >> 2, total = rows * c4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+      const int64_t q = e % c4;
+      const float4 v = reinterpret_cast<const float4 *>(x)[e];
+      float4 a = reinterpret_cast<const float4 *>(p0)[q];
+      float4 b = reinterpret_cast<const float4 *>(p1)[q];
+      if (TRAIN) {  // p0 = mean, p1 = rstd
+        const float4 g = reinterpret_cast<const float4 *>(gamma)[q];
+        const float4 bt = reinterpret_cast<const float4 *>(beta)[q];
+        const float4 sc = make_float4(b.x * g.x, b.y * g.y, b.z * g.z, b.w * g.w);
+        b = make_float4(bt.x - a.x * sc.x, bt.y - a.y * sc.y, bt.z - a.z * sc.z, bt.w - a.w * sc.w);
+        a = sc;
+      }
+      float4 o;
+      o.x = tv_lrelu(fmaf(v.x, a.x, b.x), slope);
+      o.y = tv_lrelu(fmaf(v.y, a.y, b.y), slope);
+      o.z = tv_lrelu(fmaf(v.z, a.z, b.z), slope);
+      o.w = tv_lrelu(fmaf(v.w, a.w, b.w), slope);
+      reinterpret_cast<float4 *>(y)[e] = o;
+    }
+  } else {
+    const int64_t total = rows * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+      const int64_t c = e % C;
+      float a = p0[c], b = p1[c];
+      if (TRAIN) {
+        const float sc = b * gamma[c];
+        b = beta[c] - a * sc;
+        a = sc;
+      }
+      y[e] = tv_lrelu(fmaf(x[e], a, b), slope);
+    }
+  }
+}
+
+// backward, stage 1: partial column sums of dyl = dy*lrelu'(pre) and dyl*xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    int64_t rows, int64_t C, const float *__restrict__ x, const float *__restrict__ dy,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+    float *__restrict__ partial) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nblk = gridDim.y, by = blockIdx.y;
+  if (col >= C) return;
+  const float m = mean[col], rs = rstd[col], g = gamma[col], b = beta[col];
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t r = by; r < rows; r += nblk) {
+    const float xh = (x[r * C + col] - m) * rs;
+    const float pre = fmaf(g, xh, b);
+    const float dyl = dy[r * C + col] * (pre > 0.f ? 1.f : slope);
+    s1 += dyl;
+    s2 = fmaf(dyl, xh, s2);
+  }
+  partial[(by * 2 + 0) * C + col] = s1;
+  partial[(by * 2 + 1) * C + col] = s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int64_t C, int64_t nblk,
+                                                              const float *__restrict__ partial,
+                                                              float *sums, float *dgamma,
+                                                              float *dbeta) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t b = 0; b < nblk; ++b) {
+    s1 += (double)partial[(b * 2 + 0) * C + col];
+    s2 += (double)partial[(b * 2 + 1) * C + col];
+  }
+  sums[col] = (float)s1;
+  sums[C + col] = (float)s2;
+  dbeta[col] = (float)s1;
+  dgamma[col] = (float)s2;
+}
+
+// backward, stage 2: dx = gamma*rstd*(dyl - mean(dyl) - xhat*mean(dyl*xhat))
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    int64_t rows, int64_t C, const float *__restrict__ x, const float *__restrict__ dy,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+    const float *__restrict__ sums, float inv_n, float *__restrict__ dx) {
+  const int64_t total = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t c = e % C;
+    const float rs = rstd[c], g = gamma[c];
+    const float xh = (x[e] - mean[c]) * rs;
+    const float pre = fmaf(g, xh, beta[c]);
+    const float dyl = dy[e] * (pre > 0.f ? 1.f : slope);
+    dx[e] = g * rs * (dyl - sums[c] * inv_n - xh * sums[C + c] * inv_n);
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_lrelu_bwd_kernel(
+    int64_t rows, int64_t C, const float *__restrict__ x, const float *__restrict__ dy,
+    const float *__restrict__ scale, const float *__restrict__ shift, float slope,
+    float *__restrict__ dx) {
+  const int64_t total = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t c = e % C;
+    const float pre = fmaf(x[e], scale[c], shift[c]);
+    dx[e] = dy[e] * (pre > 0.f ? 1.f : slope) * scale[c];
+  }
+}
+
+inline unsigned ew_blocks(int64_t work_items) {
+  int64_t b = tv_cdiv(work_items, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+inline bool vec_ok(int64_t C, const void *a, const void *b) {
+  return (C % 4 == 0) && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int tv_colstats(int64_t rows, int64_t cols, const float *x, float *partial,
+                           void *stream) {
+  TV_REQUIRE(rows >= 1 && cols >= 1, "tv_colstats: empty input");
+  TV_REQUIRE(x && partial, "tv_colstats: null pointer");
+  const dim3 grid((unsigned)tv_cdiv(cols, 256), (unsigned)tv_stat_blocks_host(rows));
+  hipLaunchKernelGGL(colstats_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, cols, x,
+                     partial);
+  TV_LAUNCH_CHECK("tv_colstats");
+  return TV_OK;
+}
+
+extern "C" int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, int64_t count,
+                              float eps, float momentum, float *mean, float *rstd,
+                              float *running_mean, float *running_var, void *stream) {
+  TV_REQUIRE(cols >= 1 && nblk >= 1 && count >= 1, "tv_bn_finalize: bad sizes");
+  TV_REQUIRE(partial && mean && rstd, "tv_bn_finalize: null pointer");
+  TV_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+             "tv_bn_finalize: running_mean and running_var go together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)tv_cdiv(cols, 256)), dim3(256), 0,
+                     (hipStream_t)stream, cols, nblk, partial, (double)count, eps, momentum, mean,
+                     rstd, running_mean, running_var);
+  TV_LAUNCH_CHECK("tv_bn_finalize");
+  return TV_OK;
+}
+
+extern "C" int tv_bn_apply_lrelu(int64_t rows, int64_t cols, const float *x, const float *mean,
+                                 const float *rstd, const float *gamma, const float *beta,
+                                 float slope, float *y, void *stream) {
+  TV_REQUIRE(rows >= 0 && cols >= 1, "tv_bn_apply_lrelu: bad sizes");
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(x && mean && rstd && gamma && beta && y, "tv_bn_apply_lrelu: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (vec_ok(cols, x, y) && vec_ok(cols, mean, rstd) && vec_ok(cols, gamma, beta))
+    hipLaunchKernelGGL((affine_lrelu_kernel<true, true>), dim3(ew_blocks(rows * cols / 4)),
+                       dim3(256), 0, s, rows, cols, x, mean, rstd, gamma, beta, slope, y);
+  else
+    hipLaunchKernelGGL((affine_lrelu_kernel<false, true>), dim3(ew_blocks(rows * cols)), dim3(256),
+                       0, s, rows, cols, x, mean, rstd, gamma, beta, slope, y);
+  TV_LAUNCH_CHECK("tv_bn_apply_lrelu");
+  return TV_OK;
+}
+
+extern "C" int tv_bn_eval_coeffs(int64_t cols, const float *running_mean, const float *running_var,
+                                 const float *gamma, const float *beta, float eps, float *scale,
+                                 float *shift, void *stream) {
+  TV_REQUIRE(cols >= 1, "tv_bn_eval_coeffs: bad size");
+  TV_REQUIRE(running_mean && running_var && gamma && beta && scale && shift,
+             "tv_bn_eval_coeffs: null pointer");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)tv_cdiv(cols, 256)), dim3(256), 0,
+                     (hipStream_t)stream, cols, running_mean, running_var, gamma, beta, eps, scale,
+                     shift);
+  TV_LAUNCH_CHECK("tv_bn_eval_coeffs");
+  return TV_OK;
+}
+
+extern "C" int tv_affine_lrelu(int64_t rows, int64_t cols, const float *x, const float *scale,
+                               const float *shift, float slope, float *y, void *stream) {
+  TV_REQUIRE(rows >= 0 && cols >= 1, "tv_affine_lrelu: bad sizes");
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(x && scale && shift && y, "tv_affine_lrelu: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (vec_ok(cols, x, y) && vec_ok(cols, scale, shift))
+    hipLaunchKernelGGL((affine_lrelu_kernel<true, false>), dim3(ew_blocks(rows * cols / 4)),
+                       dim3(256), 0, s, rows, cols, x, scale, shift, nullptr, nullptr, slope, y);
+  else
+    hipLaunchKernelGGL((affine_lrelu_kernel<false, false>), dim3(ew_blocks(rows * cols)),
+                       dim3(256), 0, s, rows, cols, x, scale, shift, nullptr, nullptr, slope, y);
+  TV_LAUNCH_CHECK("tv_affine_lrelu");
+  return TV_OK;
+}
+
+extern "C" int64_t tv_bn_lrelu_bwd_workspace_bytes(int64_t rows, int64_t cols) {
+  return (int64_t)sizeof(float) * (tv_stat_blocks_host(rows) * 2 * cols + 2 * cols);
+}
+
+extern "C" int tv_bn_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float *dy,
+                               const float *mean, const float *rstd, const float *gamma,
+                               const float *beta, float slope, float *dx, float *dgamma,
+                               float *dbeta, void *workspace, int64_t workspace_bytes,
+                               void *stream) {
+  TV_REQUIRE(rows >= 1 && cols >= 1, "tv_bn_lrelu_bwd: bad sizes");
+  TV_REQUIRE(x && dy && mean && rstd && gamma && beta && dx && dgamma && dbeta,
+             "tv_bn_lrelu_bwd: null pointer");
+  const int64_t need = tv_bn_lrelu_bwd_workspace_bytes(rows, cols);
+  if (!workspace || workspace_bytes < need) {
+    tv_set_error("tv_bn_lrelu_bwd: workspace of %lld bytes needed, %lld given", (long long)need,
+                 (long long)workspace_bytes);
+    return TV_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nblk = tv_stat_blocks_host(rows);
+  float *partial = (float *)workspace;
+  float *sums = partial + nblk * 2 * cols;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)tv_cdiv(cols, 256), (unsigned)nblk),
+                     dim3(256), 0, s, rows, cols, x, dy, mean, rstd, gamma, beta, slope, partial);
+  TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(reduce)");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)tv_cdiv(cols, 256)), dim3(256), 0, s,
+                     cols, nblk, partial, sums, dgamma, dbeta);
+  TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(finalize)");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, s, rows,
+                     cols, x, dy, mean, rstd, gamma, beta, slope, sums, 1.0f / (float)rows, dx);
+  TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(apply)");
+  return TV_OK;
+}
+
+extern "C" int tv_affine_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float *dy,
+                                   const float *scale, const float *shift, float slope, float *dx,
+                                   void *stream) {
+  TV_REQUIRE(rows >= 0 && cols >= 1, "tv_affine_lrelu_bwd: bad sizes");
+  if (rows == 0) return TV_OK;
+  TV_REQUIRE(x && dy && scale && shift && dx, "tv_affine_lrelu_bwd: null pointer");
+  hipLaunchKernelGGL(affine_lrelu_bwd_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0,
+                     (hipStream_t)stream, rows, cols, x, dy, scale, shift, slope, dx);
+  TV_LAUNCH_CHECK("tv_affine_lrelu_bwd");
+  return TV_OK;
+}

@@ -1,0 +1,150 @@
+// Optimizer over one flat fp32 parameter buffer: L2 term / gradient, global gradient norm
+// (two fixed-order stages, float64 partials), clip + RMSprop / Adam update in one pass.
+// HBM-bound: the update reads p, g, state and writes p, state: 20 B (RMSprop) or 28 B (Adam)
+// per parameter.
+#include "tv_common.h"
+
+namespace {
+
+constexpr int RB_THREADS = 256;
+constexpr int64_t RB_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(RB_THREADS) void sumsq_partial_kernel(int64_t n,
+                                                                   const float *__restrict__ x,
+                                                                   const uint8_t *__restrict__ mask,
+                                                                   double *__restrict__ partial) {
+  __shared__ double red[RB_THREADS];
+  float acc = 0.f;
+  double dacc = 0.0;
+  int cnt = 0;
+  for (int64_t i = (int64_t)blockIdx.x * RB_THREADS + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * RB_THREADS) {
+    const float v = (mask == nullptr || mask[i]) ? x[i] : 0.f;
+    acc = fmaf(v, v, acc);
+    if (++cnt == 64) { dacc += (double)acc; acc = 0.f; cnt = 0; }
+  }
+  red[threadIdx.x] = dacc + (double)acc;
+  __syncthreads();
+  for (int s = RB_THREADS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(RB_THREADS) void sum_partials_kernel(int64_t nblk,
+                                                                  const double *__restrict__ partial,
+                                                                  int take_sqrt,
+                                                                  float *__restrict__ out) {
+  __shared__ double red[RB_THREADS];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < nblk; i += RB_THREADS) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = RB_THREADS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(take_sqrt ? sqrt(red[0]) : red[0]);
+}
+
+__global__ __launch_bounds__(256) void axpy_masked_kernel(int64_t n, float alpha,
+                                                          const float *__restrict__ x,
+                                                          const uint8_t *__restrict__ mask,
+                                                          float *__restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (mask == nullptr || mask[i]) y[i] = fmaf(alpha, x[i], y[i]);
+}
+
+__global__ __launch_bounds__(256) void optim_step_kernel(int kind, int64_t n, float *__restrict__ p,
+                                                         const float *__restrict__ g,
+                                                         float *__restrict__ s1,
+                                                         float *__restrict__ s2,
+                                                         const float *__restrict__ grad_norm,
+                                                         float clip_norm, float lr, float beta1,
+                                                         float beta2, float eps, float bc1,
+                                                         float bc2_sqrt) {
+  float coef = 1.0f;
+  if (grad_norm != nullptr && clip_norm > 0.f) {
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+    coef = fminf(clip_norm / (grad_norm[0] + 1e-6f), 1.0f);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    if (kind == 0) {  // RMSprop: sq = a*sq + (1-a)*g^2 ; p -= lr * g / (sqrt(sq) + eps)
+      const float sq = beta2 * s1[i] + (1.0f - beta2) * gi * gi;
+      s1[i] = sq;
+      p[i] -= lr * gi / (sqrtf(sq) + eps);
+    } else {          // Adam with bias correction
+      const float m = beta1 * s1[i] + (1.0f - beta1) * gi;
+      const float v = beta2 * s2[i] + (1.0f - beta2) * gi * gi;
+      s1[i] = m;
+      s2[i] = v;
+      p[i] -= (lr / bc1) * m / (sqrtf(v) / bc2_sqrt + eps);
+    }
+  }
+}
+
+inline int64_t reduce_blocks(int64_t n) {
+  int64_t b = tv_cdiv(n, (int64_t)RB_THREADS * 16);
+  if (b < 1) b = 1;
+  if (b > RB_MAX_BLOCKS) b = RB_MAX_BLOCKS;
+  return b;
+}
+
+inline unsigned ew_blocks(int64_t n) {
+  int64_t b = tv_cdiv(n, 256 * 4);
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int64_t tv_reduce_blocks(int64_t n) { return reduce_blocks(n); }
+
+extern "C" int tv_sumsq_partial(int64_t n, const float *x, const uint8_t *mask, double *partial,
+                                void *stream) {
+  TV_REQUIRE(n >= 1 && x && partial, "tv_sumsq_partial: bad arguments");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)reduce_blocks(n)), dim3(RB_THREADS), 0,
+                     (hipStream_t)stream, n, x, mask, partial);
+  TV_LAUNCH_CHECK("tv_sumsq_partial");
+  return TV_OK;
+}
+
+extern "C" int tv_sum_partials(int64_t nblk, const double *partial, int take_sqrt, float *out,
+                               void *stream) {
+  TV_REQUIRE(nblk >= 1 && partial && out, "tv_sum_partials: bad arguments");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(RB_THREADS), 0, (hipStream_t)stream, nblk,
+                     partial, take_sqrt, out);
+  TV_LAUNCH_CHECK("tv_sum_partials");
+  return TV_OK;
+}
+
+extern "C" int tv_axpy_masked(int64_t n, float alpha, const float *x, const uint8_t *mask, float *y,
+                              void *stream) {
+  TV_REQUIRE(n >= 1 && x && y, "tv_axpy_masked: bad arguments");
+  hipLaunchKernelGGL(axpy_masked_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, n,
+                     alpha, x, mask, y);
+  TV_LAUNCH_CHECK("tv_axpy_masked");
+  return TV_OK;
+}
+
+extern "C" int tv_optim_step(int kind, int64_t n, float *param, const float *grad, float *state1,
+                             float *state2, const float *grad_norm, float clip_norm, float lr,
+                             float beta1, float beta2, float eps, int64_t step, void *stream) {
+  TV_REQUIRE(kind == 0 || kind == 1, "tv_optim_step: kind must be 0 (RMSprop) or 1 (Adam)");
+  TV_REQUIRE(n >= 1 && param && grad && state1, "tv_optim_step: bad arguments");
+  TV_REQUIRE(kind == 0 || state2, "tv_optim_step: Adam needs two state buffers");
+  TV_REQUIRE(step >= 1, "tv_optim_step: step counts from 1");
+  float bc1 = 1.0f, bc2s = 1.0f;
+  if (kind == 1) {
+    bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  }
+  hipLaunchKernelGGL(optim_step_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, kind,
+                     n, param, grad, state1, state2, grad_norm, clip_norm, lr, beta1, beta2, eps,
+                     bc1, bc2s);
+  TV_LAUNCH_CHECK("tv_optim_step");
+  return TV_OK;
+}
