@@ -1,0 +1,228 @@
+"""Throughput bench of the TraceVAE hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the training hot path over one mini-batch of synthetic trace graphs
+already resident in HBM: batch build (tv_batch_build) + q/p forward + backward + L2 +
+gradient all-reduce (N > 1) + global-norm clip + optimizer update.  Workload = BASELINE.json
+configs[1]: synthetic traces with <= 100 spans, 1k-operation vocabulary, default TraceVAE
+dims with the train.sh overrides, MAX_NODE_COUNT = 100.  Weak scaling: every rank runs the
+same per-GPU batch.  Rank 0 prints ONE JSON line; it also carries
+
+  roofline     - the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs / HIP-event time
+  cpu_baseline - the CPU oracle (a port: the reference cannot run here) on a bounded sample
+  scoring      - K-sample NLL scoring throughput (the second half of BASELINE.json's metric)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, fp32 matrix (dense)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-size', type=int, default=512, help='traces per GPU per step')
+    ap.add_argument('--max-node-count', type=int, default=100)
+    ap.add_argument('--num-operations', type=int, default=1001)
+    ap.add_argument('--pool', type=int, default=2048, help='synthetic traces generated per rank')
+    ap.add_argument('--score-k', type=int, default=10, help='n_z of the scoring leg (0 = skip)')
+    ap.add_argument('--score-batch', type=int, default=128)
+    ap.add_argument('--score-steps', type=int, default=3)
+    ap.add_argument('--cpu-baseline-traces', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--seed', type=int, default=1234)
+    return ap.parse_args()
+
+
+def make_config():
+    from tracevae_amd.config import ExpConfig, parse_flags
+    cfg = ExpConfig()
+    parse_flags(cfg, ['--model.struct.z_dim=10', '--model.struct.decoder.use_prior_flow=true',
+                      '--train.z_unit_ball_reg=1', '--model.latency.z2_dim=10',
+                      '--model.latency.decoder.condition_on_z=true'])
+    return cfg
+
+
+def cpu_baseline(cfg, flat, lr, V, M, n_traces, threads):
+    """The CPU oracle's train step (forward + backward + clip + RMSprop) on `n_traces` traces
+    of the same synthetic set: a bounded sample (about 10-30 s of CPU work)."""
+    from oracle.batching import build_batch
+    from oracle.model import OracleTraceVAE
+    from tracevae_amd.model import TraceVAE
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import oracle_state, subset_flat
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    vae = TraceVAE(cfg.model, V, max_node_count=M)
+    for m in vae.modules():
+        if hasattr(m, 'initialized'):
+            m.initialized = True
+    P, buf, names = oracle_state(vae, torch.float32)
+    params = [P[n] for n in names]
+    opt = torch.optim.RMSprop(params, lr=1e-3, alpha=0.99, eps=1e-8)
+    orc = OracleTraceVAE(cfg.model, V, M, dtype=torch.float32)
+    mean, std = lr.tables(V)
+    sub = subset_flat(flat, np.arange(n_traces))
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        ob = build_batch(sub.node_offsets, sub.u, sub.v, sub.node_type, sub.avg_latency,
+                         sub.max_latency, sub.min_latency, mean, std, M)
+        ob['node_offsets'] = sub.node_offsets
+        eps_z, eps_z2 = torch.randn(n_traces, 10), torch.randn(n_traces, 10)
+        opt.zero_grad()
+        out = orc.train_step(P, buf, ob, eps_z, eps_z2, names, l2_reg=cfg.train.l2_reg,
+                             z_unit_ball_reg=1.0)
+        out['loss'].backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {'value': n_traces / best, 'unit': 'traces/s', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle train step (batch build + fwd + bwd + clip + RMSprop) on '
+                      f'{n_traces} traces of the same synthetic set, best of 2 after 1 warm-up'}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    from tracevae_amd import ops
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    from tracevae_amd.evaluation import eval_step
+    from tracevae_amd.model import TraceVAE
+    from tracevae_amd.synth import SyntheticSpec, generate_flat
+    from tracevae_amd.train import Trainer
+
+    V, M, B = args.num_operations, args.max_node_count, args.batch_size
+    cfg = make_config()
+    spec = SyntheticSpec(num_operations=V, max_spans=M, seed=args.seed)
+    # every rank generates its own shard of the synthetic set (seeded by rank)
+    flat, lr = generate_flat(spec, args.pool, seed=args.seed + 1 + rank)
+    store = DeviceTraceStore(flat, lr, V)
+    torch.manual_seed(args.seed)          # identical initial weights on every rank
+    vae = TraceVAE(cfg.model, V, max_node_count=M).to(dev)
+    for m in vae.modules():
+        if hasattr(m, 'initialized'):
+            m.initialized = True
+    trainer = Trainer(vae, cfg, world_size=world)
+    rng = np.random.RandomState(args.seed + rank)
+
+    def train_one():
+        ids = rng.randint(0, len(store), size=B)
+        G = TraceGraphBatch.from_store(store, ids, M)
+        return trainer.step(G, check_nan=False)['loss']
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_one()
+    barrier()
+    ops.TIMER.reset()
+    ops.TIMER.enabled = True
+    t0 = time.perf_counter()
+    losses = [train_one() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER.enabled = False
+    kernel_summary = ops.TIMER.summary()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_vals = torch.stack(losses).cpu().numpy()
+    if not np.all(np.isfinite(loss_vals)):
+        raise RuntimeError(f'non-finite training loss in the timed region: {loss_vals}')
+
+    # ---- scoring leg (not part of `value`; reported next to it)
+    scoring = None
+    if args.score_k > 0 and rank == 0:
+        vae.eval()
+        SB, K = args.score_batch, args.score_k
+        def score_one():
+            ids = rng.randint(0, len(store), size=SB)
+            return eval_step(vae, TraceGraphBatch.from_store(store, ids, M), K,
+                             latency_log_prob_weight=True, clip_nll=100_000.0)[1]
+        score_one()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.score_steps):
+            score_one()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - ts
+        scoring = {'metric': 'nll_scoring_traces_per_sec', 'value': SB * args.score_steps / dt,
+                   'unit': 'traces/s', 'n_z': K, 'batch': SB, 'n_gpus': 1,
+                   'ms_per_step': 1e3 * dt / args.score_steps}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        value = B * world * args.steps / elapsed
+        g = kernel_summary.get('gemm_f32', (0, 0.0, 0.0))
+        roof = None
+        if g[2] > 0:
+            tf = g[1] / (g[2] * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel', 'achieved': tf,
+                    'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': tf / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'launches': g[0], 'avg_ms': g[2] / max(g[0], 1),
+                    'share_of_step': g[2] * 1e-3 / elapsed}
+        others = {}
+        for name in ('gat_aggregate_fwd', 'gat_aggregate_bwd'):
+            if name in kernel_summary and kernel_summary[name][2] > 0:
+                c, w, ms = kernel_summary[name]
+                others[name] = {'bound': 'hbm', 'achieved': w / (ms * 1e-3) / 1e9,
+                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                'frac': w / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'launches': c,
+                                'avg_ms': ms / c, 'share_of_step': ms * 1e-3 / elapsed}
+        line = {
+            'metric': 'train_step_traces_per_sec', 'value': value, 'unit': 'traces/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: synthetic traces <=100 spans, '
+                                   '1k-op vocab, default TraceVAE dims (train.sh flags), '
+                                   'MAX_NODE_COUNT=100, training step',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'max_node_count': M,
+                       'num_operations': V, 'pool_traces_per_gpu': args.pool,
+                       'parallelism': f'dp{world}'},
+            'roofline': roof, 'other_kernels': others, 'scoring': scoring,
+            'final_loss': float(loss_vals[-1]),
+        }
+        if not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            line['cpu_baseline'] = cpu_baseline(cfg, flat, lr, V, M, args.cpu_baseline_traces, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

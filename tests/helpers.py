@@ -1,0 +1,104 @@
+"""Shared builders for the parity tests: seeded synthetic batches, small model configs and
+the oracle <-> product plumbing."""
+import numpy as np
+import torch
+
+from tracevae_amd.config import ExpConfig, parse_flags
+from tracevae_amd.data import FlatTraces, TraceGraphLatencyRangeFile
+from tracevae_amd.synth import SyntheticSpec, generate_flat
+
+TRAIN_SH_FLAGS = ('--model.struct.z_dim=10 --model.struct.decoder.use_prior_flow=true '
+                  '--train.z_unit_ball_reg=1 --model.latency.z2_dim=10 '
+                  '--model.latency.decoder.condition_on_z=true').split()
+
+
+def make_config(width=None, layers=None, flags=TRAIN_SH_FLAGS, extra=()):
+    """ExpConfig with the train.sh overrides; `width` / `layers` shrink the GNN stacks
+    (per-head width, number of GAT layers) for fast tests."""
+    cfg = ExpConfig()
+    parse_flags(cfg, list(flags) + list(extra))
+    mc = cfg.model
+    if width is not None or layers is not None:
+        for sec in (mc.struct.encoder, mc.struct.decoder, mc.latency.encoder, mc.latency.decoder):
+            n = layers if layers is not None else len(sec.gnn_layers)
+            w = width if width is not None else sec.gnn_layers[0]
+            sec.gnn_layers = [w] * n
+    return cfg
+
+
+def make_flat(num_traces, num_operations, max_nodes, seed=3, anomaly_ratio=0.0):
+    spec = SyntheticSpec(num_operations=num_operations, max_spans=max_nodes, seed=seed)
+    return generate_flat(spec, num_traces, anomaly_ratio=anomaly_ratio)
+
+
+def hand_made_flat(shapes, num_operations, seed=0):
+    """Traces with a prescribed topology: each item of `shapes` is a parent list
+    (parent[j] for node j+1, BFS-numbered so parent[j] <= j)."""
+    rng = np.random.default_rng(seed)
+    off, us, vs = [0], [], []
+    for parents in shapes:
+        n = len(parents) + 1
+        off.append(off[-1] + n)
+        us.append(np.asarray(parents, dtype=np.int64))
+        vs.append(np.arange(1, n, dtype=np.int64))
+    n_total = off[-1]
+    node_type = rng.integers(1, num_operations, size=n_total).astype(np.int64)
+    lat = np.exp(rng.normal(2.0, 0.5, size=n_total)).astype(np.float32)
+    flat = FlatTraces(
+        node_offsets=np.asarray(off, dtype=np.int64),
+        u=np.concatenate(us) if us else np.zeros(0, np.int64),
+        v=np.concatenate(vs) if vs else np.zeros(0, np.int64),
+        node_type=node_type, avg_latency=lat,
+        max_latency=(lat * 1.5).astype(np.float32), min_latency=(lat * 0.5).astype(np.float32),
+        labels=np.zeros(len(shapes), dtype=np.int64))
+    mean = rng.uniform(1.0, 20.0, size=num_operations)
+    std = rng.uniform(0.5, 5.0, size=num_operations)
+    return flat, TraceGraphLatencyRangeFile.from_tables(mean, std)
+
+
+def subset_flat(flat: FlatTraces, ids) -> FlatTraces:
+    """Gather traces `ids` into a new contiguous FlatTraces (host side)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    off = flat.node_offsets
+    counts = off[ids + 1] - off[ids]
+    new_off = np.zeros(len(ids) + 1, dtype=np.int64)
+    np.cumsum(counts, out=new_off[1:])
+    nsel = np.concatenate([np.arange(off[i], off[i + 1]) for i in ids]) if len(ids) else np.zeros(0, np.int64)
+    esel = np.concatenate([np.arange(off[i] - i, off[i + 1] - i - 1) for i in ids]) if len(ids) else np.zeros(0, np.int64)
+    return FlatTraces(
+        node_offsets=new_off, u=flat.u[esel], v=flat.v[esel], node_type=flat.node_type[nsel],
+        avg_latency=flat.avg_latency[nsel], max_latency=flat.max_latency[nsel],
+        min_latency=flat.min_latency[nsel],
+        labels=None if flat.labels is None else flat.labels[ids])
+
+
+def oracle_batch(flat: FlatTraces, latency_range, num_operations, max_node_count):
+    from oracle.batching import build_batch
+    mean, std = latency_range.tables(num_operations)
+    b = build_batch(flat.node_offsets, flat.u, flat.v, flat.node_type, flat.avg_latency,
+                    flat.max_latency, flat.min_latency, mean, std, max_node_count)
+    b['node_offsets'] = flat.node_offsets
+    return b
+
+
+def oracle_state(vae, dtype=torch.float32):
+    """(params with requires_grad, buffers, trainable names) from the product module."""
+    sd = vae.state_dict()
+    names = [n for n, _ in vae.named_parameters()]
+    P, buf = {}, {}
+    for k, v in sd.items():
+        v = v.detach().cpu()
+        if 'running_' in k or 'num_batches_tracked' in k:
+            buf[k] = v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()
+        else:
+            P[k] = v.clone().to(dtype)
+    for n in names:
+        P[n].requires_grad_(True)
+    return P, buf, names
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    denom = b.abs().max().clamp(min=1e-12)
+    return float((a - b).abs().max() / denom)

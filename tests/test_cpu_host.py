@@ -1,0 +1,199 @@
+"""CPU suite, part 2: host logic without a GPU - the C-ABI library loads and exports every
+symbol of include/tracevae_hip.h, argument validation, config / flag parsing, state_dict
+layout, the flat parameter bucket, and the data-parallel gradient exchange over gloo with
+two ranks."""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tracevae_amd import hip
+    text = open(hip.header_path()).read()
+    declared = set(re.findall(r'\b(tv_\w+)\s*\(', re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)))
+    assert len(declared) >= 40
+    assert declared == set(hip.SIGNATURES)
+    lib = hip.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.tv_version() == 1
+    assert hip.query('tv_stat_blocks', 1) == 1 and hip.query('tv_stat_blocks', 10 ** 9) == 768
+    assert hip.query('tv_gemm_f32_workspace_bytes', 51200, 1000, 1000) == 0
+    assert hip.query('tv_gemm_f32_workspace_bytes', 1000, 1000, 51200) > 0
+
+
+def test_host_side_validation_without_gpu():
+    """Bad shapes are rejected before any launch (so these calls are safe on a CPU box)."""
+    from tracevae_amd import hip
+    lib = hip.lib()
+    one = 4096   # never dereferenced: validation fails first
+    assert lib.tv_gemm_f32(0, 1, 4, 4, 4, one, 2, one, 4, one, 4, None, None, 0, None, 0, None) == -1
+    assert b'lda' in lib.tv_last_error()
+    assert lib.tv_gat_scores(10, 9, 8, one, one, one, one, one, None) == -1
+    assert lib.tv_gat_scores(10, 2, 6, one, one, one, one, one, None) == -1
+    assert lib.tv_adj_bernoulli_ll_fwd(1, 2, 8, 500, one, one, 0, 1.0, 0.0, one, None) == -1
+    assert lib.tv_rowdot_fwd(5, 10, 9, one, one, None, one, None) == -1
+    assert lib.tv_optim_step(3, 10, one, one, one, None, None, 0.0, 1e-3, 0.0, 0.99, 1e-8, 1, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from tracevae_amd import hip, ops
+    with pytest.raises(hip.HipLibraryError):
+        ops.gemm(torch.zeros(2, 2), torch.zeros(2, 2), False, False)
+    from tracevae_amd.batch import DeviceTraceStore
+    from helpers import make_flat
+    flat, lr = make_flat(2, 10, 4)
+    with pytest.raises(hip.HipLibraryError):
+        DeviceTraceStore(flat, lr, 10)
+
+
+def test_config_flags_and_json_round_trip():
+    from tracevae_amd.config import ExpConfig, config_from_dict, config_to_dict, parse_flags
+    cfg = make_config()
+    assert cfg.model.struct.z_dim == 10 and cfg.model.struct.decoder.use_prior_flow is True
+    assert cfg.train.z_unit_ball_reg == 1 and cfg.model.latency.decoder.condition_on_z is True
+    assert cfg.train.batch_size == 64 and cfg.train.optimizer == 'rmsprop'
+    assert cfg.model.struct.encoder.gnn_layers == [500, 500, 500, 500]
+    rest = parse_flags(cfg, ['--device=cpu', '--dataset.root_dir=/x', '--seed=1234',
+                             '--train.warm_up_epochs=none', '--model.struct.encoder.gnn_layers=[8,8]'])
+    assert rest == [] and cfg.seed == 1234 and cfg.dataset.root_dir == '/x'
+    assert cfg.model.struct.encoder.gnn_layers == [8, 8]
+    with pytest.raises(AttributeError):
+        parse_flags(cfg, ['--model.no_such_field=1'])
+    blob = json.loads(json.dumps(config_to_dict(cfg)))
+    again = config_from_dict(ExpConfig(), blob)
+    assert config_to_dict(again) == config_to_dict(cfg)
+    # instances do not share mutable defaults
+    other = ExpConfig()
+    assert other.model.struct.encoder.gnn_layers == [500, 500, 500, 500]
+
+
+def test_state_dict_layout_matches_appendix_c():
+    from tracevae_amd.model import TraceVAE
+    cfg = make_config(width=8, layers=4)
+    vae = TraceVAE(cfg.model, 50, max_node_count=8)
+    sd = vae.state_dict()
+    emb = [k for k in sd if k.endswith('node_embedding.weight')]
+    assert sorted(emb) == ['latency_vae.operation_embedding.node_embedding.weight',
+                           'operation_embedding.node_embedding.weight',
+                           'struct_vae.operation_embedding.node_embedding.weight']
+    assert sd[emb[0]].data_ptr() == sd[emb[1]].data_ptr() == sd[emb[2]].data_ptr()
+    for stack in ('struct_vae.qz_gnn_layers', 'struct_vae.pG_node_type_logits',
+                  'latency_vae.qz2_gnn_layers', 'latency_vae.pG_node_features'):
+        for i in range(4):
+            assert sd[f'{stack}.gnn.{i}.gnn.fc.weight'].shape[0] == 16
+            assert sd[f'{stack}.gnn.{i}.gnn.attn_l'].shape == (1, 2, 8)
+            assert sd[f'{stack}.gnn.{i}.gnn.bias'].shape == (16,)
+            for leaf in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+                assert f'{stack}.gnn.{i}.normalization.{leaf}' in sd
+    assert sd['struct_vae.pG_node_type_logits.gnn.4.gnn.weight'].shape == (16, 50)
+    assert sd['latency_vae.pG_node_features.gnn.4.gnn.weight'].shape == (16, 2)
+    assert sd['struct_vae.qz_mean.weight_store.value'].shape == (10, 16)
+    assert sd['struct_vae.pG_node_embedding.weight_store.value'].shape == (8 * 40, 500)
+    assert sd['struct_vae.pG_node_count_logits.layer.1.bias_store.value'].shape == (9,)
+    assert 'struct_vae.pz_flow.original_flow.flows.2.kernel' in sd
+    # named_parameters de-duplicates the shared embedding; L2 skips names containing 'bias'
+    names = [n for n, _ in vae.named_parameters()]
+    assert names.count('operation_embedding.node_embedding.weight') == 1
+    assert not any('struct_vae.operation_embedding' in n for n in names)
+    # strict load of its own state dict
+    vae2 = TraceVAE(cfg.model, 50, max_node_count=8)
+    vae2.load_state_dict(sd, strict=True)
+
+
+def test_flat_parameters_and_phase2_quirk():
+    from tracevae_amd.model import TraceVAE
+    from tracevae_amd.train import FlatParameters, l2_parameter_names, learning_rate_for_epoch
+    cfg = make_config(width=8, layers=2)
+    vae = TraceVAE(cfg.model, 30, max_node_count=8)
+    before = {n: p.detach().clone() for n, p in vae.named_parameters()}
+    flat = FlatParameters(vae)
+    for n, p in vae.named_parameters():
+        assert torch.equal(p.detach(), before[n])
+        a, b = flat.slices[n]
+        assert p.data_ptr() == flat.flat.data_ptr() + 4 * a and a % 64 == 0
+        assert p.grad.data_ptr() == flat.grad.data_ptr() + 4 * a
+        assert (a >= flat.tail_start) == n.startswith('latency_vae.')
+    # writing through the flat buffer is visible in the module (and in state_dict)
+    flat.flat.fill_(0.5)
+    assert float(vae.state_dict()['struct_vae.qz_mean.weight_store.value'].mean()) == 0.5
+    # the reference zips trained parameters with the full name list (train.py:253-255)
+    all_names = flat.all_names
+    part = [n for n in all_names if n.startswith('latency_vae.')]
+    l2 = l2_parameter_names(all_names, part)
+    assert l2 == [p for p, n in zip(part, all_names) if 'bias' not in n]
+    assert l2_parameter_names(all_names, all_names) == [n for n in all_names if 'bias' not in n]
+    assert learning_rate_for_epoch(cfg.train, 1) == 1e-3
+    assert abs(learning_rate_for_epoch(cfg.train, 30) - 1e-4) < 1e-12
+    assert abs(learning_rate_for_epoch(cfg.train, 60) - 1e-5) < 1e-12
+
+
+def _dp_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from tracevae_amd.model import TraceVAE
+    from tracevae_amd.train import Trainer
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    cfg = make_config(width=8, layers=2)
+    vae = TraceVAE(cfg.model, 30, max_node_count=8)
+    trainer = Trainer(vae, cfg, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(trainer.flat.total, generator=g)
+    trainer.flat.grad.copy_(local)
+    trainer.all_reduce_gradients()
+    torch.save({'local': local, 'reduced': trainer.flat.grad.clone()}, os.path.join(tmp, f'r{rank}.pt'))
+    # phase 2 only exchanges the latency_vae suffix of the bucket
+    trainer.set_phase(latency_only=True)
+    trainer.flat.grad.copy_(local)
+    trainer.all_reduce_gradients()
+    torch.save({'reduced': trainer.flat.grad.clone(), 'tail': trainer.flat.tail_start},
+               os.path.join(tmp, f'p2_r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_bucket_allreduce_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, 29000 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
+    mean = (r[0]['local'] + r[1]['local']) / 2
+    for i in range(world):
+        assert torch.allclose(r[i]['reduced'], mean, atol=1e-7)
+    assert torch.equal(r[0]['reduced'], r[1]['reduced'])
+    p2 = [torch.load(tmp_path / f'p2_r{i}.pt') for i in range(world)]
+    tail = p2[0]['tail']
+    for i in range(world):
+        assert torch.equal(p2[i]['reduced'][:tail], r[i]['local'][:tail])      # untouched
+        assert torch.allclose(p2[i]['reduced'][tail:], mean[tail:], atol=1e-7)
+
+
+def test_store_stream_shards_batches_across_ranks():
+    from tracevae_amd.train import StoreStream
+
+    class FakeStore(object):
+        labels = None
+
+        def __len__(self):
+            return 103
+
+    seen = []
+    for rank in range(4):
+        s = StoreStream(FakeStore(), 10, shuffle=True, seed=7, rank=rank, world_size=4)
+        ids = [G._trace_ids for G in s]
+        assert len(ids) == s.batch_count
+        seen += ids
+    allids = np.concatenate(seen)
+    assert sorted(allids.tolist()) == list(range(103))        # a partition of the data set

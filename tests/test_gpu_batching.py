@@ -1,0 +1,109 @@
+"""(a) batching: tv_batch_build against the NumPy oracle - every index array bit-exact, the
+float outputs bit-exact too (float64 normalisation, then one cast)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import hand_made_flat, make_flat, oracle_batch, subset_flat
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ['enc_src', 'enc_dst', 'enc_indptr', 'enc_indices', 'enc_eids', 'enc_rev',
+            'dec_src', 'dec_dst', 'dec_indptr', 'dec_indices', 'dec_eids', 'dec_rev']
+
+
+def _device_batch_arrays(db):
+    out = {}
+    for name in ('src', 'dst', 'indptr', 'indices', 'eids', 'rev'):
+        out['enc_' + name] = getattr(db.enc, name)
+        out['dec_' + name] = getattr(db.dec, name)
+    for name in ('adj', 'node_type_pad', 'latency_pad', 'node_count', 'node_type', 'latency',
+                 'graph_id'):
+        out[name] = getattr(db, name)
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _compare(flat, lr, V, M, ids=None):
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    store = DeviceTraceStore(flat, lr, V)
+    if ids is None:
+        ids = np.arange(len(flat))
+    db = TraceGraphBatch.from_store(store, ids, M).build_dgl()
+    got = _device_batch_arrays(db)
+    want = oracle_batch(subset_flat(flat, ids), lr, V, M)
+    for k in INT_KEYS + ['node_type_pad', 'node_count', 'node_type', 'graph_id']:
+        assert got[k].dtype == np.int64, k
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    for k in ('adj', 'latency_pad', 'latency'):
+        assert got[k].dtype == np.float32, k
+        np.testing.assert_array_equal(got[k].view(np.uint32), want[k].view(np.uint32), err_msg=k)
+
+
+def test_synthetic_batches(device):
+    flat, lr = make_flat(64, 200, 32, seed=11)
+    _compare(flat, lr, 200, 32)
+    # a shuffled subset, gathered out of the store by index
+    ids = np.random.RandomState(0).permutation(64)[:23]
+    _compare(flat, lr, 200, 32, ids)
+
+
+def test_edge_topologies(device):
+    M = 12
+    shapes = [
+        [0],                                  # n = 2 (smallest trace the reference keeps)
+        [0] * (M - 1),                        # star with n = M
+        list(range(M - 1)),                   # chain with n = M
+        [0, 0, 1, 1, 2, 2, 3],                # binary-ish tree
+        [0, 1, 1, 1, 2, 5],                   # mixed
+    ]
+    flat, lr = hand_made_flat(shapes, 30, seed=5)
+    _compare(flat, lr, 30, M)
+    _compare(flat, lr, 30, M, ids=[4, 0, 0, 2])     # repeats and reordering
+
+
+def test_large_max_node_count(device):
+    flat, lr = make_flat(8, 500, 100, seed=2)
+    _compare(flat, lr, 500, 100)
+    _compare(flat, lr, 500, 500)                     # long-trace configuration (C5 shape)
+
+
+def test_empty_batch(device):
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    flat, lr = make_flat(4, 50, 8, seed=1)
+    store = DeviceTraceStore(flat, lr, 50)
+    db = TraceGraphBatch.from_store(store, np.zeros(0, np.int64), 8).build_dgl()
+    assert db.batch_size == 0 and db.num_nodes == 0
+    assert db.enc.indptr.cpu().tolist() == [0] and db.dec.indptr.cpu().tolist() == [0]
+
+
+def test_errors(device):
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    from tracevae_amd.data import TraceGraphLatencyRangeFile
+    flat, lr = hand_made_flat([[0, 0, 1], [0]], 20, seed=3)
+    store = DeviceTraceStore(flat, lr, 20)
+    with pytest.raises(ValueError):                  # more nodes than MAX_NODE_COUNT
+        TraceGraphBatch.from_store(store, [0, 1], 3).build_dgl()
+    # an operation missing from latency_range: the reference raises KeyError (dataset.py:77)
+    mean, std = lr.tables(20)
+    mean[int(flat.node_type[1])] = np.nan
+    store2 = DeviceTraceStore(flat, TraceGraphLatencyRangeFile.from_tables(mean, std), 20)
+    with pytest.raises(KeyError):
+        TraceGraphBatch.from_store(store2, [0, 1], 8).build_dgl()
+
+
+def test_from_trace_graph_objects(device):
+    """The reference's constructor form: a list of TraceGraph objects."""
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.data import flatten_trace_graphs
+    from tracevae_amd.synth import SyntheticSpec, generate_trace_graphs, make_latency_range
+    spec = SyntheticSpec(num_operations=80, max_spans=20, seed=9)
+    graphs = generate_trace_graphs(spec, 10)
+    lr = make_latency_range(spec)
+    G = TraceGraphBatch(latency_range=lr, trace_graphs=graphs, num_operations=80)
+    G._max_node_count = 20
+    db = G.build_dgl()
+    want = oracle_batch(flatten_trace_graphs(graphs), lr, 80, 20)
+    got = _device_batch_arrays(db)
+    for k in INT_KEYS:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    np.testing.assert_array_equal(got['adj'], want['adj'])

@@ -1,0 +1,185 @@
+"""Path-level parity (north_star bound: losses and per-trace scores within 1e-4 relative, fp32):
+the product model on the HIP kernels against the CPU oracle on the same batch, the same
+weights and the same epsilon draws.  The float64 oracle is the arbiter; the float32 oracle
+run is reported next to it."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (make_config, make_flat, oracle_batch, oracle_state, rel_err, subset_flat)
+
+pytestmark = pytest.mark.gpu
+PATH_TOL = 1e-4
+
+
+def _setup(device, V, M, width, layers, batch, seed=0, extra=(), anomaly_ratio=0.0):
+    from tracevae_amd.batch import DeviceTraceStore
+    from tracevae_amd.model import TraceVAE
+    torch.manual_seed(seed)
+    cfg = make_config(width=width, layers=layers, extra=extra)
+    vae = TraceVAE(cfg.model, V, max_node_count=M)
+    # make BatchNorm / ActNorm state non-trivial so that eval mode is a real test
+    with torch.no_grad():
+        for name, buf in vae.named_buffers():
+            if name.endswith('running_mean'):
+                buf.normal_(0, 0.1)
+            elif name.endswith('running_var'):
+                buf.uniform_(0.5, 1.5)
+        for name, p in vae.named_parameters():
+            if name.endswith('pre_scale') or (name.endswith('.bias') and 'flows' in name):
+                p.normal_(0, 0.1)
+            if 'branches' in name and name.endswith('weight_store.value'):
+                p.normal_(0, 0.05)
+    for m in vae.modules():
+        if hasattr(m, 'initialized'):
+            m.initialized = True
+    flat, lr = make_flat(batch, V, M, seed=seed + 5, anomaly_ratio=anomaly_ratio)
+    P, buf, names = oracle_state(vae, torch.float64)
+    vae.to(device)
+    store = DeviceTraceStore(flat, lr, V)
+    return cfg, vae, store, flat, lr, P, buf, names
+
+
+@pytest.mark.parametrize('V,M,width,layers,batch', [(60, 16, 16, 2, 9), (300, 32, 500, 4, 16)])
+def test_train_step_loss_and_gradients(device, V, M, width, layers, batch):
+    from oracle.model import OracleTraceVAE
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.train import Trainer
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, width, layers, batch)
+    B = len(flat)
+    g = torch.Generator().manual_seed(1)
+    eps_z = torch.randn(B, cfg.model.struct.z_dim, generator=g)
+    eps_z2 = torch.randn(B, cfg.model.latency.z2_dim, generator=g)
+
+    orc = OracleTraceVAE(cfg.model, V, M, dtype=torch.float64)
+    ob = oracle_batch(flat, lr, V, M)
+    ref = orc.train_step(P, buf, ob, eps_z.double(), eps_z2.double(), names,
+                         kl_beta=cfg.train.kl_beta, l2_reg=cfg.train.l2_reg,
+                         z_unit_ball_reg=cfg.train.z_unit_ball_reg,
+                         z2_unit_ball_reg=cfg.train.z2_unit_ball_reg)
+    ref['loss'].backward()
+
+    trainer = Trainer(vae, cfg, world_size=1)
+    G = TraceGraphBatch.from_store(store, np.arange(B), M)
+    trainer.flat.zero_grad()
+    out = trainer.forward_loss(G, eps={'z': eps_z, 'z2': eps_z2})
+    out['loss'].backward()
+    for k in ('loss', 'recons', 'kl'):
+        assert rel_err(out[k], ref[k]) < PATH_TOL, k
+    chain = out['chain']
+    for name, key in (('z', 'log_p_z'), ('node_count', 'log_p_node_count'), ('adj', 'log_p_adj'),
+                      ('node_type', 'log_p_node_type'), ('z2', 'log_p_z2'),
+                      ('latency', 'log_p_latency')):
+        assert rel_err(chain.p[name].log_prob(), ref['p'][key]) < PATH_TOL, name
+    assert rel_err(chain.q['z'].log_prob(), ref['q']['log_q_z']) < PATH_TOL
+    assert rel_err(chain.q['z2'].log_prob(), ref['q']['log_q_z2']) < PATH_TOL
+    # gradients of every parameter (before the L2 term, which the trainer adds separately:
+    # remove it from the oracle gradient)
+    l2_names = set(trainer.l2_names)
+    worst = 0.0
+    for n, p in vae.named_parameters():
+        want = P[n].grad
+        if n in l2_names:
+            want = want - 2.0 * cfg.train.l2_reg * P[n].detach()
+        scale = max(float(want.abs().max()), 1e-6)
+        err = float((p.grad.double().cpu() - want).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 20 * PATH_TOL, (n, err)
+    # BatchNorm running statistics moved the same way
+    sd = vae.state_dict()
+    for k, v in buf.items():
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            assert rel_err(sd[k], v) < PATH_TOL, k
+
+
+@pytest.mark.parametrize('use_flow', [True, False])
+def test_eval_step_scores(device, use_flow):
+    from oracle.model import OracleTraceVAE
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.evaluation import eval_step
+    V, M, K = 80, 20, 5
+    extra = () if use_flow else ('--model.struct.decoder.use_prior_flow=false',)
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 24, 2, 11, seed=3, extra=extra,
+                                                       anomaly_ratio=0.3)
+    vae.eval()
+    B = len(flat)
+    g = torch.Generator().manual_seed(2)
+    eps_z, eps_z2 = torch.randn(K, B, 10, generator=g), torch.randn(K, B, 10, generator=g)
+    std_limit = torch.rand(V, generator=g) * 0.5 + 0.05
+    orc = OracleTraceVAE(cfg.model, V, M, dtype=torch.float64)
+    ob = oracle_batch(flat, lr, V, M)
+    ref = orc.eval_step(P, buf, ob, eps_z.double(), eps_z2.double(), use_biased=True,
+                        use_latency_biased=True, latency_log_prob_weight=True,
+                        std_limit=std_limit.double(), clip_nll=100_000.0)
+    G = TraceGraphBatch.from_store(store, np.arange(B), M)
+    loss, nll, chain = eval_step(vae, G, K, use_biased=True, use_latency_biased=True,
+                                 latency_log_prob_weight=True, std_limit=std_limit.to(device),
+                                 clip_nll=100_000.0, eps={'z': eps_z, 'z2': eps_z2},
+                                 return_chain=True)
+    assert rel_err(nll, ref['nll']) < PATH_TOL
+    assert rel_err(loss, ref['loss']) < PATH_TOL
+    # the reference-style accessors give the same numbers
+    assert rel_err(-chain.vi.evaluation.is_loglikelihood(), ref['nll'].clamp(max=1e30)) < PATH_TOL
+    assert rel_err(chain.p['latency'].distribution.base_distribution.std,
+                   torch.exp(ref['p']['latency_logstd'])) < PATH_TOL
+    # scoring is per trace: a batch split in two gives the same scores (no cross-trace coupling)
+    half = B // 2
+    e1 = {'z': eps_z[:, :half], 'z2': eps_z2[:, :half]}
+    e2 = {'z': eps_z[:, half:], 'z2': eps_z2[:, half:]}
+    kw = dict(use_biased=True, use_latency_biased=True, latency_log_prob_weight=True,
+              std_limit=std_limit.to(device), clip_nll=100_000.0)
+    _, n1 = eval_step(vae, TraceGraphBatch.from_store(store, np.arange(half), M), K, eps=e1, **kw)
+    _, n2 = eval_step(vae, TraceGraphBatch.from_store(store, np.arange(half, B), M), K, eps=e2, **kw)
+    assert rel_err(torch.cat([n1, n2]), nll) < 1e-5
+
+
+def test_trainer_step_matches_oracle_update(device):
+    """One full optimisation step (forward, backward, L2, clip, RMSprop) against the oracle +
+    torch.optim.RMSprop on the CPU."""
+    from oracle.model import OracleTraceVAE
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.train import Trainer
+    V, M = 60, 16
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 2, 8, seed=7)
+    B = len(flat)
+    g = torch.Generator().manual_seed(4)
+    eps_z, eps_z2 = torch.randn(B, 10, generator=g), torch.randn(B, 10, generator=g)
+    orc = OracleTraceVAE(cfg.model, V, M, dtype=torch.float64)
+    ob = oracle_batch(flat, lr, V, M)
+    params = [P[n] for n in names]
+    ropt = torch.optim.RMSprop(params, lr=cfg.train.initial_lr, alpha=0.99, eps=1e-8)
+    ref = orc.train_step(P, buf, ob, eps_z.double(), eps_z2.double(), names,
+                         l2_reg=cfg.train.l2_reg, z_unit_ball_reg=cfg.train.z_unit_ball_reg)
+    ref['loss'].backward()
+    torch.nn.utils.clip_grad_norm_(params, cfg.train.global_clip_norm)
+    before = {n: P[n].detach().clone() for n in names}
+    ropt.step()
+
+    trainer = Trainer(vae, cfg, world_size=1)
+    G = TraceGraphBatch.from_store(store, np.arange(B), M)
+    out = trainer.step(G, eps={'z': eps_z, 'z2': eps_z2})
+    assert rel_err(out['loss'], ref['loss']) < PATH_TOL
+    for n, p in vae.named_parameters():
+        want_delta = P[n].detach() - before[n]
+        got_delta = p.detach().double().cpu() - before[n]
+        scale = max(float(want_delta.abs().max()), 1e-9)
+        assert float((got_delta - want_delta).abs().max()) / scale < 5e-3, n
+
+
+def test_phase2_latency_only(device):
+    """Phase 2 (train.py:204-208, 472-487): struct_vae in eval mode, only latency_vae.* moves."""
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.train import Trainer
+    V, M = 60, 16
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 2, 8, seed=9)
+    trainer = Trainer(vae, cfg, latency_only=True, world_size=1)
+    before = {n: p.detach().clone() for n, p in vae.named_parameters()}
+    rm_before = {k: v.clone() for k, v in vae.state_dict().items() if k.endswith('running_mean')}
+    G = TraceGraphBatch.from_store(store, np.arange(len(flat)), M)
+    trainer.step(G)
+    moved = {n for n, p in vae.named_parameters() if not torch.equal(p.detach(), before[n])}
+    assert moved and all(n.startswith('latency_vae.') for n in moved)
+    sd = vae.state_dict()
+    for k, v in rm_before.items():
+        changed = not torch.equal(sd[k], v)
+        assert changed == k.startswith('latency_vae.'), k

@@ -1,0 +1,470 @@
+"""Operator-level parity: every HIP kernel, called through the C-ABI (`tracevae_amd.ops`),
+against the oracle's restatement of the same operator evaluated in float64 on the CPU.
+Tolerance: 1e-5 relative to the largest reference magnitude (fp32 kernels vs a float64
+reference; the path-level bound of north_star is 1e-4)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import hand_made_flat, make_flat, oracle_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+def _dev(t, device):
+    return t.to(torch.float32).to(device).contiguous()
+
+
+# --------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('m,n,k', [(1, 1, 1), (7, 5, 3), (64, 10, 1000), (130, 257, 41),
+                                   (300, 1000, 1000), (1000, 1000, 50), (33, 1001, 1000),
+                                   (513, 129, 36), (256, 256, 32)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm(device, m, n, k, ta, tb):
+    from tracevae_amd import ops
+    a = _rand(*((k, m) if ta else (m, k)), seed=1)
+    b = _rand(*((n, k) if tb else (k, n)), seed=2)
+    bias = _rand(n, seed=3)
+    ref = (a.t() if ta else a) @ (b.t() if tb else b) + bias
+    got = ops.gemm(_dev(a, device), _dev(b, device), ta, tb, bias=_dev(bias, device))
+    assert rel_err(got, ref) < TOL
+
+
+def test_gemm_split_k_and_accumulate(device):
+    from tracevae_amd import ops
+    # weight-gradient shape: small output, long reduction -> split-K path
+    a, b = _rand(20000, 96, seed=4), _rand(20000, 200, seed=5)
+    ref = a.t() @ b
+    got = ops.gemm(_dev(a, device), _dev(b, device), True, False)
+    assert rel_err(got, ref) < TOL
+    again = ops.gemm(_dev(a, device), _dev(b, device), True, False)
+    assert torch.equal(got, again)                       # fixed-order reduction: bit-stable
+    c0 = _rand(96, 200, seed=6)
+    c = _dev(c0, device)
+    scale = _rand(96, seed=7)
+    ops.gemm(_dev(a, device), _dev(b, device), True, False, row_scale=_dev(scale, device), out=c,
+             accumulate=True)
+    assert rel_err(c, c0 + scale[:, None] * ref) < TOL
+
+
+def test_gemm_asymmetric_identity(device):
+    """A = I with an asymmetric B catches a transposed accumulator layout."""
+    from tracevae_amd import ops
+    n = 96
+    b = torch.arange(n * 70, dtype=torch.float64).reshape(n, 70) % 17 - 3.0
+    got = ops.gemm(_dev(torch.eye(n, dtype=torch.float64), device), _dev(b, device), False, False)
+    assert torch.equal(got.cpu().double(), b)
+
+
+def test_linear_autograd(device):
+    from tracevae_amd import ops
+    x, w, b = _rand(37, 5, 41, seed=1), _rand(29, 41, seed=2), _rand(29, seed=3)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.linear(xr, wr, br)
+    g = _rand(*ref.shape, seed=4)
+    ref.backward(g)
+    xd, wd, bd = (_dev(t, device).requires_grad_(True) for t in (x, w, b))
+    got = ops.linear(xd, wd, bd)
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL
+    assert rel_err(xd.grad, xr.grad) < TOL and rel_err(wd.grad, wr.grad) < TOL
+    assert rel_err(bd.grad, br.grad) < TOL
+
+
+def test_matmul_nn_and_rowdot_autograd(device):
+    from tracevae_amd import ops
+    x, w, b = _rand(301, 64, seed=1), _rand(64, 131, seed=2), _rand(131, seed=3)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = xr @ wr + br
+    g = _rand(*ref.shape, seed=4)
+    ref.backward(g)
+    xd, wd, bd = (_dev(t, device).requires_grad_(True) for t in (x, w, b))
+    got = ops.matmul_nn(xd, wd, bd)
+    got.backward(_dev(g, device))
+    for a_, b_ in ((got, ref), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert rel_err(a_, b_) < TOL
+    # skinny head
+    x, w = _rand(515, 1000, seed=5), _rand(1000, 2, seed=6)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = xr @ wr
+    g = _rand(515, 2, seed=7)
+    ref.backward(g)
+    xd, wd = _dev(x, device).requires_grad_(True), _dev(w, device).requires_grad_(True)
+    got = ops.rowdot(xd, wd)
+    got.backward(_dev(g, device))
+    for a_, b_ in ((got, ref), (xd.grad, xr.grad), (wd.grad, wr.grad)):
+        assert rel_err(a_, b_) < TOL
+
+
+# ---------------------------------------------------------------------------------- GAT
+def _graph(device, num_traces=12, V=40, M=16, seed=7, shapes=None):
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    if shapes is None:
+        flat, lr = make_flat(num_traces, V, M, seed=seed)
+    else:
+        flat, lr = hand_made_flat(shapes, V, seed=seed)
+    store = DeviceTraceStore(flat, lr, V)
+    db = TraceGraphBatch.from_store(store, np.arange(len(flat)), M).build_dgl()
+    ob = oracle_batch(flat, lr, V, M)
+    return db, ob
+
+
+@pytest.mark.parametrize('heads,feats', [(2, 500), (2, 8), (1, 64), (2, 1000)])
+@pytest.mark.parametrize('which', ['enc', 'dec'])
+def test_gat_conv_forward_backward(device, heads, feats, which):
+    from oracle.model import gat_conv
+    from tracevae_amd import ops
+    db, ob = _graph(device)
+    graph = getattr(db, which)
+    src, dst = torch.as_tensor(ob[which + '_src']), torch.as_tensor(ob[which + '_dst'])
+    rows = graph.num_rows
+    ft = _rand(rows, heads * feats, seed=1)
+    al, ar = _rand(1, heads, feats, seed=2, scale=0.3), _rand(1, heads, feats, seed=3, scale=0.3)
+    bias = _rand(heads * feats, seed=4)
+    g = _rand(rows, heads * feats, seed=5)
+
+    ftr, alr, arr, br = (t.clone().requires_grad_(True) for t in (ft, al, ar, bias))
+    # the oracle takes h and a weight; feed ft through an identity weight
+    eye = torch.eye(heads * feats, dtype=torch.float64)
+    ref = gat_conv(ftr, src, dst, eye, alr, arr, br, heads).reshape(rows, -1)
+    ref.backward(g)
+
+    ftd, ald, ard, bd = (_dev(t, device).requires_grad_(True) for t in (ft, al, ar, bias))
+    got, stats = ops.gat_conv(ftd, ald, ard, bd, graph, 1, want_stats=True)
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL
+    assert rel_err(ftd.grad, ftr.grad) < TOL
+    assert rel_err(ald.grad, alr.grad) < TOL and rel_err(ard.grad, arr.grad) < TOL
+    assert rel_err(bd.grad, br.grad) < TOL
+    # fused column statistics of the output
+    s = stats.double().sum(0).cpu()
+    assert rel_err(s[0], ref.detach().sum(0)) < TOL
+    assert rel_err(s[1], (ref.detach() ** 2).sum(0)) < TOL
+    # determinism: bit-equal on a second run
+    got2, _ = ops.gat_conv(ftd.detach(), ald.detach(), ard.detach(), bd.detach(), graph, 1)
+    assert torch.equal(got2, got.detach())
+
+
+def test_gat_high_degree(device):
+    """A star with more than 64 leaves exercises the multi-chunk edge loops."""
+    from oracle.model import gat_conv
+    from tracevae_amd import ops
+    n = 150
+    db, ob = _graph(device, V=30, M=n, shapes=[[0] * (n - 1), [0, 0, 1]])
+    heads, feats = 2, 16
+    for which in ('enc', 'dec'):
+        graph = getattr(db, which)
+        src, dst = torch.as_tensor(ob[which + '_src']), torch.as_tensor(ob[which + '_dst'])
+        rows = graph.num_rows
+        ft = _rand(rows, heads * feats, seed=1)
+        al, ar = _rand(1, heads, feats, seed=2), _rand(1, heads, feats, seed=3)
+        bias = _rand(heads * feats, seed=4)
+        g = _rand(rows, heads * feats, seed=5)
+        ftr, alr, arr, br = (t.clone().requires_grad_(True) for t in (ft, al, ar, bias))
+        ref = gat_conv(ftr, src, dst, torch.eye(heads * feats, dtype=torch.float64), alr, arr, br,
+                       heads).reshape(rows, -1)
+        ref.backward(g)
+        ftd, ald, ard, bd = (_dev(t, device).requires_grad_(True) for t in (ft, al, ar, bias))
+        got, _ = ops.gat_conv(ftd, ald, ard, bd, graph, 1)
+        got.backward(_dev(g, device))
+        assert rel_err(got, ref) < TOL
+        assert rel_err(ftd.grad, ftr.grad) < TOL
+        assert rel_err(ald.grad, alr.grad) < TOL and rel_err(ard.grad, arr.grad) < TOL
+
+
+def test_gat_replicas_and_eval_epilogue(device):
+    """K replicas of the decoder graph in one launch + fused eval BatchNorm/LeakyReLU."""
+    from oracle.model import gat_conv
+    from tracevae_amd import ops
+    db, ob = _graph(device)
+    heads, feats, K = 2, 12, 3
+    graph = db.dec
+    src, dst = torch.as_tensor(ob['dec_src']), torch.as_tensor(ob['dec_dst'])
+    rows = graph.num_rows
+    ft = _rand(K * rows, heads * feats, seed=1)
+    al, ar = _rand(1, heads, feats, seed=2), _rand(1, heads, feats, seed=3)
+    bias, scale, shift = _rand(heads * feats, seed=4), _rand(heads * feats, seed=5), _rand(heads * feats, seed=6)
+    eye = torch.eye(heads * feats, dtype=torch.float64)
+    ref = torch.cat([gat_conv(ft[k * rows:(k + 1) * rows], src, dst, eye, al, ar, bias, heads)
+                     .reshape(rows, -1) for k in range(K)])
+    ref = F.leaky_relu(ref * scale + shift, 0.01)
+    with torch.no_grad():
+        got, _ = ops.gat_conv(_dev(ft, device), _dev(al, device), _dev(ar, device), _dev(bias, device),
+                              graph, K, ep_scale=_dev(scale, device), ep_shift=_dev(shift, device),
+                              ep_slope=0.01)
+    assert rel_err(got, ref) < TOL
+
+
+# --------------------------------------------------------------------------- BatchNorm
+@pytest.mark.parametrize('rows,cols', [(300, 1000), (77, 250), (5000, 16)])
+def test_bn_lrelu_train_and_eval(device, rows, cols):
+    from tracevae_amd import ops
+    x = _rand(rows, cols, seed=1) * 2 + 0.5
+    gamma, beta = _rand(cols, seed=2), _rand(cols, seed=3)
+    rm, rv = _rand(cols, seed=4), _rand(cols, seed=5).abs() + 0.5
+    g = _rand(rows, cols, seed=6)
+    eps = 1e-6
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.leaky_relu(F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, eps), 0.01)
+    ref.backward(g)
+    xd, gd, bd = (_dev(t, device).requires_grad_(True) for t in (x, gamma, beta))
+    rmd, rvd = _dev(rm, device), _dev(rv, device)
+    got = ops.bn_lrelu(xd, gd, bd, rmd, rvd, True, eps)
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL
+    assert rel_err(xd.grad, xr.grad) < 5 * TOL
+    assert rel_err(gd.grad, gr.grad) < TOL and rel_err(bd.grad, br.grad) < TOL
+    assert rel_err(rmd, rm_ref) < TOL and rel_err(rvd, rv_ref) < TOL
+    # eval mode
+    xr2 = x.clone().requires_grad_(True)
+    ref2 = F.leaky_relu(F.batch_norm(xr2, rm, rv, gamma, beta, False, 0.1, eps), 0.01)
+    ref2.backward(g)
+    xd2 = _dev(x, device).requires_grad_(True)
+    got2 = ops.bn_lrelu(xd2, _dev(gamma, device), _dev(beta, device), _dev(rm, device),
+                        _dev(rv, device), False, eps)
+    got2.backward(_dev(g, device))
+    assert rel_err(got2, ref2) < TOL and rel_err(xd2.grad, xr2.grad) < TOL
+
+
+# ------------------------------------------------------- GraphConv / readout / embedding
+def test_graph_sum_segment_mean_embedding(device):
+    from oracle.model import avg_pooling, graph_conv
+    from tracevae_amd import ops
+    db, ob = _graph(device)
+    for which in ('enc', 'dec'):
+        graph = getattr(db, which)
+        src, dst = torch.as_tensor(ob[which + '_src']), torch.as_tensor(ob[which + '_dst'])
+        rows = graph.num_rows
+        for cols, out_cols in ((64, 80), (64, 2)):
+            x, w, b = _rand(rows, cols, seed=1), _rand(cols, out_cols, seed=2), _rand(out_cols, seed=3)
+            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            ref = graph_conv(xr, src, dst, wr, b)
+            g = _rand(rows, out_cols, seed=4)
+            ref.backward(g)
+            xd, wd = _dev(x, device).requires_grad_(True), _dev(w, device).requires_grad_(True)
+            if cols > out_cols:
+                got = ops.graph_sum(ops.rowdot(xd, wd), graph) + _dev(b, device)
+            else:
+                got = ops.matmul_nn(ops.graph_sum(xd, graph), wd, _dev(b, device))
+            got.backward(_dev(g, device))
+            assert rel_err(got, ref) < TOL
+            assert rel_err(xd.grad, xr.grad) < TOL and rel_err(wd.grad, wr.grad) < TOL
+    # readout
+    rows = db.enc.num_rows
+    x = _rand(rows, 1000, seed=5)
+    xr = x.clone().requires_grad_(True)
+    ref = avg_pooling(xr, ob['node_offsets'])
+    g = _rand(*ref.shape, seed=6)
+    ref.backward(g)
+    xd = _dev(x, device).requires_grad_(True)
+    got = ops.segment_mean(xd, db.node_offsets, db.graph_id)
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL and rel_err(xd.grad, xr.grad) < TOL
+    # embedding gather + per-operation segmented sum
+    w = _rand(40, 40, seed=7)
+    wr = w.clone().requires_grad_(True)
+    ids = torch.as_tensor(ob['node_type'])
+    ref = wr[ids]
+    g = _rand(*ref.shape, seed=8)
+    ref.backward(g)
+    wd = _dev(w, device).requires_grad_(True)
+    got = ops.embedding(wd, db.node_type)
+    got.backward(_dev(g, device))
+    assert torch.equal(got.detach().cpu().double(), ref.detach().float().double())
+    assert rel_err(wd.grad, wr.grad) < TOL
+
+
+def test_latdec_input(device):
+    from tracevae_amd import ops
+    db, ob = _graph(device)
+    K, B, M = 3, db.batch_size, db.max_node_count
+    z2, emb = _rand(K, B, 10, seed=1), _rand(40, 40, seed=2)
+    ntp = torch.as_tensor(ob['node_type_pad'])
+    z2r = z2.clone().requires_grad_(True)
+    ref = torch.cat([z2r.unsqueeze(-2).expand(K, B, M, 10), emb[ntp].expand(K, B, M, 40)], -1)
+    ref = ref.reshape(K * B * M, 50)
+    g = _rand(*ref.shape, seed=3)
+    ref.backward(g)
+    z2d = _dev(z2, device).requires_grad_(True)
+    got = ops.latdec_input(z2d.reshape(-1, 10), _dev(emb, device), db.node_type_pad, K)
+    got.backward(_dev(g, device))
+    assert torch.equal(got.detach().cpu(), ref.detach().float())
+    assert rel_err(z2d.grad, z2r.grad) < TOL
+
+
+# -------------------------------------------------------------------------- likelihoods
+@pytest.mark.parametrize('M,D,K,biased', [(16, 40, 1, False), (16, 40, 3, True), (100, 40, 2, True),
+                                          (70, 80, 1, False)])
+def test_adj_bernoulli_ll(device, M, D, K, biased):
+    from oracle.model import bernoulli_log_prob, biased as biased_fn, dense_to_triu
+    from tracevae_amd import ops
+    B = 5
+    T = M * (M - 1) // 2
+    h = _rand(K * B, M, D, seed=1, scale=0.4)
+    adj = (torch.rand(B, T, generator=torch.Generator().manual_seed(2)) < 0.05).double()
+    hr = h.clone().requires_grad_(True)
+    logits = dense_to_triu(hr @ hr.transpose(-1, -2), M).reshape(K, B, T)
+    lp = bernoulli_log_prob(adj, logits)
+    if biased:
+        lp = biased_fn(lp, M, 0.5)
+    ref = lp.sum(-1).reshape(-1)
+    g = _rand(K * B, seed=3)
+    ref.backward(g)
+    hd = _dev(h, device).requires_grad_(True)
+    got = ops.adj_bernoulli_ll(hd, _dev(adj, device), K, biased, float(M), 0.5)
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL
+    assert rel_err(hd.grad, hr.grad) < 5 * TOL
+
+
+@pytest.mark.parametrize('V,biased', [(1001, False), (33, True), (1488, False)])
+def test_categorical_ll(device, V, biased):
+    from oracle.model import biased as biased_fn, categorical_log_prob
+    from tracevae_amd import ops
+    K, R = 3, 50
+    logits = _rand(K * R, V, seed=1, scale=3.0)
+    target = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(2))
+    lr_ = logits.clone().requires_grad_(True)
+    ref = categorical_log_prob(target.repeat(K), lr_)
+    if biased:
+        ref = biased_fn(ref, 1024.0, 0.5)
+    g = _rand(K * R, seed=3)
+    ref.backward(g)
+    ld = _dev(logits, device).requires_grad_(True)
+    got = ops.categorical_ll(ld, target.to(device), biased, 1024.0, 0.5)
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL and rel_err(ld.grad, lr_.grad) < TOL
+
+
+def test_normal_reparam_and_ll(device):
+    from oracle.model import normal_log_pdf
+    from tracevae_amd import ops
+    K, B, D = 4, 9, 10
+    mean, ls, eps = _rand(B, D, seed=1), _rand(B, D, seed=2, scale=3.0), _rand(K, B, D, seed=3)
+    mr, lr_ = mean.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    lsc = lr_.clamp(-7, 2)
+    z = mr + torch.exp(lsc) * eps
+    logq = normal_log_pdf(z, mr, lsc).sum(-1)
+    gz, gq = _rand(K, B, D, seed=4), _rand(K, B, seed=5)
+    (z * gz).sum().add((logq * gq).sum()).backward()
+    md, ld = _dev(mean, device).requires_grad_(True), _dev(ls, device).requires_grad_(True)
+    zd, qd, lsd = ops.normal_reparam(md, ld, _dev(eps, device), -7, 2)
+    ((zd * _dev(gz, device)).sum() + (qd * _dev(gq, device)).sum()).backward()
+    assert rel_err(zd, z) < TOL and rel_err(qd, logq) < TOL and rel_err(lsd, lsc) < TOL
+    assert rel_err(md.grad, mr.grad) < TOL and rel_err(ld.grad, lr_.grad) < 5 * TOL
+    # plain log-likelihood with clamp
+    x = _rand(K, B, D, seed=6)
+    m2, l2 = _rand(K, B, D, seed=7), _rand(K, B, D, seed=8, scale=3.0)
+    xr, m2r, l2r = (t.clone().requires_grad_(True) for t in (x, m2, l2))
+    ref = normal_log_pdf(xr, m2r, l2r.clamp(-5, 2)).sum(-1)
+    g = _rand(K, B, seed=9)
+    ref.backward(g)
+    xd, m2d, l2d = (_dev(t, device).requires_grad_(True) for t in (x, m2, l2))
+    got = ops.normal_ll(xd, m2d, l2d, -5, 2)
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL
+    for a_, b_ in ((xd.grad, xr.grad), (m2d.grad, m2r.grad), (l2d.grad, l2r.grad)):
+        assert rel_err(a_, b_) < TOL
+
+
+@pytest.mark.parametrize('mode', ['normal', 'safe', 'biased', 'anomaly'])
+@pytest.mark.parametrize('weighted,use_limit', [(False, False), (True, True)])
+def test_latency_ll(device, mode, weighted, use_limit):
+    from oracle.model import biased as biased_fn, normal_log_pdf
+    from tracevae_amd import ops
+    K, B, M, V = 2, 6, 12, 20
+    feats = _rand(K * B * M, 2, seed=1, scale=2.0)
+    x = _rand(B, M, 1, seed=2, scale=3.0)
+    node_count = torch.randint(2, M + 1, (B,), generator=torch.Generator().manual_seed(3))
+    ntp = torch.randint(0, V, (B, M), generator=torch.Generator().manual_seed(4))
+    std_limit = (_rand(V, seed=5).abs() + 0.05) if use_limit else None
+    thr, alpha = (6.0, 1.0) if mode == 'safe' else (1.5, float(M))
+
+    fr = feats.clone().requires_grad_(True)
+    mu = fr[:, 0].reshape(K, B, M, 1)
+    ls = fr[:, 1].reshape(K, B, M, 1).clamp(min=-7)
+    if use_limit:
+        ls = torch.minimum(ls, torch.log(std_limit[ntp].clamp(min=1e-7)).unsqueeze(-1))
+    sd = torch.exp(ls)
+    if mode == 'safe':
+        lo, hi = (mu - thr * sd).detach(), (mu + thr * sd).detach()
+        lp = normal_log_pdf(torch.maximum(torch.minimum(x, hi), lo), mu, ls)
+    elif mode == 'biased':
+        lp = normal_log_pdf(x, mu, ls)
+        lp = torch.where((x - mu).abs() > thr * sd, lp * alpha, lp)
+    elif mode == 'anomaly':
+        t = ((x - mu) / sd).abs() - thr
+        lp = biased_fn(-math.log(2.0) + torch.log1p(-torch.erf(t / math.sqrt(2.0))), alpha, 0.5)
+    else:
+        lp = normal_log_pdf(x, mu, ls)
+    mask = (torch.arange(M).unsqueeze(0) < node_count.unsqueeze(-1)).double().unsqueeze(-1)
+    lp = lp * mask
+    if weighted:
+        lp = lp * (float(M) / node_count.double()).reshape(-1, 1, 1)
+    ref = lp.sum((-1, -2)).reshape(-1)
+
+    fd = _dev(feats, device).requires_grad_(True)
+    got, std = ops.latency_ll(
+        fd, _dev(x, device), node_count.to(device), ntp.to(device), K, mode=mode,
+        std_threshold=thr, alpha=alpha, bias_threshold=0.5, logstd_min=-7,
+        std_limit=None if std_limit is None else _dev(std_limit, device), use_mask=True,
+        weighted=weighted)
+    assert rel_err(got, ref) < 2 * TOL
+    assert rel_err(std, sd.reshape(-1)) < TOL
+    if mode != 'anomaly':
+        g = _rand(K * B, seed=6)
+        ref.backward(g)
+        got.backward(_dev(g, device))
+        assert rel_err(fd.grad, fr.grad) < 2 * TOL
+
+
+def test_score_reduce(device):
+    from tracevae_amd import ops
+    w = _rand(10, 33, seed=1, scale=30.0)
+    w[3, 5] = float('nan')
+    w[:, 7] = 1e9
+    ref_loss = -w.mean(0)
+    ref_nll = -(torch.logsumexp(w, 0) - math.log(10))
+    clip = torch.tensor(100000.0, dtype=torch.float64)
+    ref_loss = torch.where(ref_loss < clip, ref_loss, clip)
+    ref_nll = torch.where(ref_nll < clip, ref_nll, clip)
+    loss, nll = ops.score_reduce(_dev(w, device), 100000.0)
+    assert rel_err(loss, ref_loss) < TOL and rel_err(nll, ref_nll) < TOL
+    assert float(nll[5]) == 100000.0                     # NaN -> clip
+
+
+# ---------------------------------------------------------------------------- optimizer
+@pytest.mark.parametrize('kind', ['rmsprop', 'adam'])
+def test_flat_optimizer(device, kind):
+    from tracevae_amd.train import FlatOptimizer, FlatParameters
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(30, 50), torch.nn.Linear(50, 7))
+    ref = torch.nn.Sequential(torch.nn.Linear(30, 50), torch.nn.Linear(50, 7))
+    ref.load_state_dict(net.state_dict())
+    net.to(device)
+    flat = FlatParameters(net, tail_prefix='1.')
+    opt = FlatOptimizer(flat, kind)
+    opt.set_lr(1e-2)
+    ropt = (torch.optim.RMSprop(ref.parameters(), lr=1e-2, alpha=0.99, eps=1e-8) if kind == 'rmsprop'
+            else torch.optim.Adam(ref.parameters(), lr=1e-2))
+    for step in range(3):
+        x = torch.randn(16, 30)
+        flat.zero_grad()
+        (net(x.to(device)) ** 2).sum().backward()
+        opt.step(10.0)
+        ropt.zero_grad()
+        (ref(x) ** 2).sum().backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0)
+        ropt.step()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert rel_err(p, q) < 1e-4, n

@@ -26,7 +26,7 @@ import yaml
 __all__ = [
     'TraceGraphNodeFeatures', 'TraceGraphNode', 'TraceGraphVectors', 'TraceGraph',
     'IDAssign', 'TraceGraphIDManager', 'TraceGraphLatencyRangeFile',
-    'FlatTraces', 'flatten_trace_graphs',
+    'FlatTraces', 'flatten_trace_graphs', 'load_trace_csv', 'df_to_trace_graphs',
 ]
 
 
@@ -181,6 +181,16 @@ class IDAssign(object):
         self._next_index = (max(self._mapping.values()) + 1) if self._mapping else 0
         self._rev_mapping = {v: k for k, v in self._mapping.items()}
 
+    @classmethod
+    def from_mapping(cls, mapping: Dict[str, int], size: Optional[int] = None) -> 'IDAssign':
+        self = cls.__new__(cls)
+        self._path = None
+        self._mapping = dict(mapping)
+        self._next_index = size if size is not None else \
+            ((max(self._mapping.values()) + 1) if self._mapping else 0)
+        self._rev_mapping = {v: k for k, v in self._mapping.items()}
+        return self
+
     def __len__(self):
         return self._next_index
 
@@ -199,6 +209,15 @@ class TraceGraphIDManager(object):
         self.root_dir = os.path.abspath(root_dir)
         self.service_id = IDAssign(os.path.join(self.root_dir, 'service_id.yml'))
         self.operation_id = IDAssign(os.path.join(self.root_dir, 'operation_id.yml'))
+
+    @classmethod
+    def from_mappings(cls, service_id: Dict[str, int], operation_id: Dict[str, int],
+                      num_operations: Optional[int] = None) -> 'TraceGraphIDManager':
+        self = cls.__new__(cls)
+        self.root_dir = None
+        self.service_id = IDAssign.from_mapping(service_id)
+        self.operation_id = IDAssign.from_mapping(operation_id, num_operations)
+        return self
 
     @property
     def num_operations(self) -> int:
@@ -316,3 +335,78 @@ def flatten_trace_graphs(trace_graphs: Sequence[TraceGraph]) -> FlatTraces:
         max_latency=cat('max_latency', np.float32), min_latency=cat('min_latency', np.float32),
         labels=labels,
     )
+
+
+# ---------------------------------------------------------------------------------------
+# CSV spans -> trace graphs (config-1 plumbing; tracegnn/data/trace_graph.py:443-617)
+# ---------------------------------------------------------------------------------------
+_CSV_COLUMNS = ['traceIdHigh', 'traceIdLow', 'spanId', 'parentSpanId', 'serviceName',
+                'operationName', 'startTime', 'duration', 'nanosecond', 'DBhash']
+_CSV_TEST_COLUMNS = ['nodeLatencyLabel', 'graphLatencyLabel', 'graphStructureLabel']
+
+
+def load_trace_csv(input_path: str, is_test: bool = False):
+    import pandas as pd
+    dtype = {c: int for c in _CSV_COLUMNS}
+    dtype.update(serviceName=str, operationName=str, startTime=str, duration=float)
+    if is_test:
+        dtype.update({c: int for c in _CSV_TEST_COLUMNS})
+    return pd.read_csv(input_path, engine='c', usecols=list(dtype), dtype=dtype)
+
+
+def df_to_trace_graphs(df, id_manager: TraceGraphIDManager, test_label: Optional[int] = None,
+                       min_node_count: int = 2, max_node_count: int = 32,
+                       merge_spans: bool = False) -> List[TraceGraph]:
+    """Spans (one row each) -> trace graphs, the way the reference's preprocessing does it:
+    rows with DBhash != 0 and spans of unknown services / operations are skipped; for test
+    files a trace is labelled 1 (structure) / 2 (latency) / 0 and only `test_label` is kept;
+    nodes attach to their parent span, orphans become roots of their own graph; nodes are
+    visited in (service id, operation id, start time) order so children lists are ordered;
+    graphs outside [min_node_count, max_node_count] are dropped (defaults 2 and 32: the
+    reference uses default arguments here, not MAX_NODE_COUNT - SURVEY.md appendix D.10)."""
+    from datetime import datetime, timedelta
+    rows = df.to_dict(orient='records') if hasattr(df, 'to_dict') else list(df)
+    traces: Dict[Tuple[int, int], Dict[int, tuple]] = {}
+    for row in rows:
+        if int(row['DBhash']) != 0:
+            continue
+        if test_label is not None:
+            label = 1 if int(row['graphStructureLabel']) != 0 else (
+                2 if int(row['graphLatencyLabel']) != 0 else 0)
+            if label != test_label:
+                continue
+        service = str(row['serviceName'])
+        operation = f"{row['serviceName']}/{row['operationName']}"
+        if service not in id_manager.service_id or operation not in id_manager.operation_id:
+            continue
+        trace_id = (int(row['traceIdHigh']), int(row['traceIdLow']))
+        start = datetime.strptime(str(row['startTime']), '%Y-%m-%d %H:%M:%S') + \
+            timedelta(microseconds=int(row['nanosecond']) / 1_000)
+        latency = float(row['duration'])
+        node = TraceGraphNode(
+            node_id=None, service_id=id_manager.service_id[service],
+            operation_id=id_manager.operation_id[operation],
+            features=TraceGraphNodeFeatures(span_count=1, avg_latency=latency,
+                                            max_latency=latency, min_latency=latency),
+            spans=[(int(row['spanId']), start, latency)])
+        traces.setdefault(trace_id, {})[int(row['spanId'])] = (int(row['parentSpanId']), node, start)
+
+    data = {} if not test_label else {
+        'is_anomaly': True, 'anomaly_type': 'drop' if test_label == 1 else 'latency'}
+    graphs: List[TraceGraph] = []
+    for trace_id, spans in traces.items():
+        ordered = sorted(spans.values(),
+                         key=lambda t: (t[1].service_id, t[1].operation_id, t[2]))
+        for parent_id, node, _start in ordered:
+            if parent_id == 0 or parent_id not in spans:
+                graphs.append(TraceGraph(version=TraceGraph.default_version(), trace_id=trace_id,
+                                         parent_id=parent_id, root=node, node_count=None,
+                                         max_depth=None, data=dict(data)))
+            else:
+                spans[parent_id][1].children.append(node)
+    for g in graphs:
+        if merge_spans:
+            g.merge_spans_and_assign_id()
+        else:
+            g.assign_node_id()
+    return [g for g in graphs if min_node_count <= g.node_count <= max_node_count]

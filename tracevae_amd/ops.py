@@ -1,0 +1,731 @@
+"""Host-side operators of the accelerated path: thin `torch.autograd.Function`s over the
+C-ABI of `libtracevae_hip.so`.  PyTorch only provides device memory, the stream and the
+autograd tape here; every operator body is a call into the HIP library (`hip.call`), and
+there is no other implementation to fall back to.
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import hip
+
+__all__ = [
+    'DeviceGraph', 'TIMER', 'gemm', 'linear', 'matmul_nn', 'rowdot', 'colsum', 'gat_conv', 'bn_lrelu',
+    'graph_sum', 'segment_mean', 'embedding', 'latdec_input', 'adj_bernoulli_ll',
+    'categorical_ll', 'normal_reparam', 'normal_ll', 'latency_ll', 'score_reduce',
+    'LATENCY_MODES',
+]
+
+_f32 = torch.float32
+
+
+class KernelTimer(object):
+    """Optional per-kernel timing with HIP events on the launch stream (bench.py turns it on
+    for the timed region): `totals[name] = [launches, work, [event pairs]]`."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def reset(self):
+        self.records = {}
+
+    class _Region(object):
+        def __init__(self, timer, name, work):
+            self.timer, self.name, self.work = timer, name, work
+
+        def __enter__(self):
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+
+        def __exit__(self, *exc):
+            self.end.record()
+            rec = self.timer.records.setdefault(self.name, [0, 0.0, []])
+            rec[0] += 1
+            rec[1] += self.work
+            rec[2].append((self.start, self.end))
+
+    class _Null(object):
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *exc):
+            return False
+
+    _null = _Null()
+
+    def region(self, name, work):
+        if not self.enabled:
+            return self._null
+        return self._Region(self, name, float(work))
+
+    def summary(self):
+        """{name: (launches, total work, total milliseconds)} - call after a device sync."""
+        out = {}
+        for name, (count, work, pairs) in self.records.items():
+            out[name] = (count, work, sum(a.elapsed_time(b) for a, b in pairs))
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def _check(t: torch.Tensor, name: str, dtype=_f32) -> torch.Tensor:
+    if not t.is_cuda:
+        raise hip.HipLibraryError(
+            f'{name} is on {t.device}: the accelerated path runs on the GPU only '
+            f'(there is no CPU fallback)')
+    if t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
+    if nbytes <= 0:
+        return None
+    return torch.empty([(nbytes + 3) // 4], dtype=_f32, device=device)
+
+
+class DeviceGraph(object):
+    """Destination-sorted CSC of a (symmetric) batched graph, as `tv_batch_build` emits it."""
+    __slots__ = ['indptr', 'indices', 'eids', 'rev', 'src', 'dst', 'num_rows', 'num_edges']
+
+    def __init__(self, indptr, indices, eids, rev, src, dst):
+        self.indptr, self.indices, self.eids, self.rev = indptr, indices, eids, rev
+        self.src, self.dst = src, dst
+        self.num_rows = int(indptr.shape[0]) - 1
+        self.num_edges = int(indices.shape[0])
+
+
+# ---------------------------------------------------------------------------------------
+# dense
+# ---------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
+         bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """C = row_scale * (op(a) @ op(b)) + bias on the fp32 MFMA kernel (`tv_gemm_f32`)."""
+    a, b = _check(a, 'a'), _check(b, 'b')
+    m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    n, kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
+    if k != kb:
+        raise ValueError(f'gemm: inner sizes differ: {k} vs {kb}')
+    c = out if out is not None else torch.empty([m, n], dtype=_f32, device=a.device)
+    if m == 0 or n == 0:
+        return c
+    if k == 0:
+        if not accumulate:
+            c.zero_()
+        return c
+    wsb = hip.query('tv_gemm_f32_workspace_bytes', m, n, k)
+    ws = _workspace(wsb, a.device)
+    with TIMER.region('gemm_f32', 2.0 * m * n * k):
+        hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr(a), a.stride(0),
+                 hip.ptr(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
+                 hip.ptr(row_scale), int(accumulate), hip.ptr(ws), wsb)
+    return c
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    x = _check(x, 'x')
+    rows, cols = x.shape
+    out = torch.empty([cols], dtype=_f32, device=x.device)
+    if rows == 0:
+        return out.zero_()
+    wsb = hip.query('tv_colsum_workspace_bytes', rows, cols)
+    ws = _workspace(wsb, x.device)
+    hip.call('tv_colsum', rows, cols, hip.ptr(x), x.stride(0), hip.ptr(out), hip.ptr(ws), wsb)
+    return out
+
+
+class _Linear(Function):
+    """y = x @ W^T + b with W stored [out, in] (torch / tensorkit Linear, GATConv.fc)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = _check(x.reshape(-1, x.shape[-1]), 'x')
+        weight = _check(weight, 'weight')
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.x_shape = x.shape
+        y = gemm(x2, weight, False, True, bias=bias)
+        return y.reshape(x.shape[:-1] + (weight.shape[0],))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = _check(dy.reshape(-1, dy.shape[-1]), 'dy')
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dy2, weight, False, False).reshape(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = gemm(dy2, x2, True, False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+class _MatmulNN(Function):
+    """y = x @ W + b with W stored [in, out] (dgl GraphConv weight layout)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = _check(x, 'x'), _check(weight, 'weight')
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return gemm(x, weight, False, False, bias=bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _check(dy, 'dy')
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dy, weight, False, True)
+        if ctx.needs_input_grad[1]:
+            dw = gemm(x, dy, True, False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)
+        return dx, dw, db
+
+
+def matmul_nn(x, weight, bias=None):
+    return _MatmulNN.apply(x, weight, bias)
+
+
+class _RowDot(Function):
+    """out[r, j] = sum_k x[r,k] w[k,j] for a skinny w (at most 8 columns)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _check(x, 'x'), _check(w, 'w')
+        rows, k = x.shape
+        n = w.shape[1]
+        out = torch.empty([rows, n], dtype=_f32, device=x.device)
+        hip.call('tv_rowdot_fwd', rows, k, n, hip.ptr(x), hip.ptr(w), None, hip.ptr(out))
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        dout = _check(dout, 'dout')
+        rows, k = x.shape
+        n = w.shape[1]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        wsb = hip.query('tv_rowdot_bwd_workspace_bytes', rows, k, n)
+        ws = _workspace(wsb, x.device)
+        hip.call('tv_rowdot_bwd', rows, k, n, hip.ptr(x), hip.ptr(w), None, hip.ptr(dout),
+                 hip.ptr(dx), hip.ptr(dw), hip.ptr(ws), wsb)
+        return dx, dw
+
+
+def rowdot(x, w):
+    return _RowDot.apply(x, w)
+
+
+# ---------------------------------------------------------------------------------------
+# GAT message passing
+# ---------------------------------------------------------------------------------------
+class _GATConv(Function):
+    @staticmethod
+    def forward(ctx, ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int, want_stats: bool,
+                ep_scale, ep_shift, ep_slope: float):
+        ft = _check(ft, 'ft')
+        heads, feats = int(attn_l.shape[-2]), int(attn_l.shape[-1])
+        rows = ft.shape[0]
+        if rows != graph.num_rows * n_rep or ft.shape[1] != heads * feats:
+            raise ValueError(f'gat_conv: ft {tuple(ft.shape)} does not match graph rows '
+                             f'{graph.num_rows} x {n_rep} / heads {heads} x feats {feats}')
+        al, ar = _check(attn_l, 'attn_l').reshape(-1), _check(attn_r, 'attn_r').reshape(-1)
+        bias = _check(bias, 'bias')
+        dev = ft.device
+        el = torch.empty([rows, heads], dtype=_f32, device=dev)
+        er = torch.empty([rows, heads], dtype=_f32, device=dev)
+        hip.call('tv_gat_scores', rows, heads, feats, hip.ptr(ft), hip.ptr(al), hip.ptr(ar),
+                 hip.ptr(el), hip.ptr(er))
+        need_grad = any(ctx.needs_input_grad[:4])
+        if need_grad and n_rep != 1:
+            raise ValueError('gat_conv: gradients are only available for a single graph replica')
+        out = torch.empty([rows, heads * feats], dtype=_f32, device=dev)
+        alpha = torch.empty([graph.num_edges, heads], dtype=_f32, device=dev) if need_grad else None
+        stats = None
+        if want_stats:
+            stats = torch.empty([hip.query('tv_stat_blocks', rows), 2, heads * feats],
+                                dtype=_f32, device=dev)
+        # algorithmic bytes: ft gathered once per in-edge + out written once (+ scores/indices)
+        hf = heads * feats
+        work = 4.0 * hf * (graph.num_edges + graph.num_rows) * n_rep \
+            + (8.0 * heads * (graph.num_edges + graph.num_rows) + 8.0 * graph.num_edges) * n_rep
+        with TIMER.region('gat_aggregate_fwd', work):
+            hip.call('tv_gat_aggregate_fwd', graph.num_rows, n_rep, heads, feats,
+                     hip.ptr(graph.indptr), hip.ptr(graph.indices), hip.ptr(ft), hip.ptr(el),
+                     hip.ptr(er), hip.ptr(bias), hip.ptr(out), hip.ptr(alpha), hip.ptr(stats),
+                     hip.ptr(ep_scale), hip.ptr(ep_shift), float(ep_slope))
+        if need_grad:
+            ctx.save_for_backward(ft, el, er, alpha, al, ar)
+            ctx.graph = graph
+            ctx.hf = (heads, feats)
+            ctx.attn_shape = attn_l.shape
+        if stats is None:
+            stats = torch.empty([0], dtype=_f32, device=dev)
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout, _dstats):
+        ft, el, er, alpha, al, ar = ctx.saved_tensors
+        g = ctx.graph
+        heads, feats = ctx.hf
+        dout = _check(dout, 'dout')
+        dev = ft.device
+        dft = torch.empty_like(ft)
+        dal = torch.empty([heads * feats], dtype=_f32, device=dev)
+        dar = torch.empty([heads * feats], dtype=_f32, device=dev)
+        dbias = torch.empty([heads * feats], dtype=_f32, device=dev)
+        wsb = hip.query('tv_gat_aggregate_bwd_workspace_bytes', g.num_rows, 1, heads, feats,
+                        g.num_edges)
+        ws = _workspace(wsb, dev)
+        # algorithmic bytes: edge pass (dout row + ft per in-edge) + node pass (dout per
+        # in-edge, ft + dout rows read, dft written)
+        hf = heads * feats
+        work = 4.0 * hf * (2 * g.num_edges + 4 * g.num_rows)
+        with TIMER.region('gat_aggregate_bwd', work):
+            hip.call('tv_gat_aggregate_bwd', g.num_rows, 1, heads, feats, g.num_edges,
+                     hip.ptr(g.indptr), hip.ptr(g.indices), hip.ptr(g.rev), hip.ptr(ft),
+                     hip.ptr(el), hip.ptr(er), hip.ptr(al), hip.ptr(ar), hip.ptr(alpha),
+                     hip.ptr(dout), hip.ptr(dft), hip.ptr(dal), hip.ptr(dar), hip.ptr(dbias),
+                     hip.ptr(ws), wsb)
+        return (dft, dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape), dbias,
+                None, None, None, None, None, None)
+
+
+def gat_conv(ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int = 1,
+             want_stats: bool = False, ep_scale=None, ep_shift=None, ep_slope: float = 0.01):
+    """GATConv message passing after the fc projection.  Returns `(out, stats_partial)`;
+    `stats_partial` is an empty tensor unless `want_stats`."""
+    return _GATConv.apply(ft, attn_l, attn_r, bias, graph, n_rep, want_stats, ep_scale, ep_shift,
+                          ep_slope)
+
+
+# ---------------------------------------------------------------------------------------
+# BatchNorm + LeakyReLU
+# ---------------------------------------------------------------------------------------
+class _BNLReLUTrain(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope, stats):
+        x = _check(x, 'x')
+        rows, cols = x.shape
+        dev = x.device
+        if rows < 2:
+            raise ValueError('Expected more than 1 value per channel when training')
+        if stats is None or stats.numel() == 0:
+            stats = torch.empty([hip.query('tv_stat_blocks', rows), 2, cols], dtype=_f32, device=dev)
+            hip.call('tv_colstats', rows, cols, hip.ptr(x), hip.ptr(stats))
+        nblk = stats.shape[0]
+        mean = torch.empty([cols], dtype=_f32, device=dev)
+        rstd = torch.empty([cols], dtype=_f32, device=dev)
+        hip.call('tv_bn_finalize', cols, nblk, hip.ptr(stats), rows, float(eps), float(momentum),
+                 hip.ptr(mean), hip.ptr(rstd), hip.ptr(running_mean), hip.ptr(running_var))
+        y = torch.empty_like(x)
+        gamma, beta = _check(gamma, 'gamma'), _check(beta, 'beta')
+        hip.call('tv_bn_apply_lrelu', rows, cols, hip.ptr(x), hip.ptr(mean), hip.ptr(rstd),
+                 hip.ptr(gamma), hip.ptr(beta), float(slope), hip.ptr(y))
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        dy = _check(dy, 'dy')
+        rows, cols = x.shape
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        wsb = hip.query('tv_bn_lrelu_bwd_workspace_bytes', rows, cols)
+        ws = _workspace(wsb, x.device)
+        hip.call('tv_bn_lrelu_bwd', rows, cols, hip.ptr(x), hip.ptr(dy), hip.ptr(mean),
+                 hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), ctx.slope, hip.ptr(dx),
+                 hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), wsb)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+class _AffineLReLU(Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, slope):
+        x = _check(x, 'x')
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        hip.call('tv_affine_lrelu', rows, cols, hip.ptr(x), hip.ptr(scale), hip.ptr(shift),
+                 float(slope), hip.ptr(y))
+        ctx.save_for_backward(x, scale, shift)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, scale, shift = ctx.saved_tensors
+        dy = _check(dy, 'dy')
+        dx = torch.empty_like(x)
+        hip.call('tv_affine_lrelu_bwd', x.shape[0], x.shape[1], hip.ptr(x), hip.ptr(dy),
+                 hip.ptr(scale), hip.ptr(shift), ctx.slope, hip.ptr(dx))
+        return dx, None, None, None
+
+
+def bn_eval_coeffs(running_mean, running_var, gamma, beta, eps: float):
+    cols = running_mean.shape[0]
+    scale = torch.empty_like(running_mean)
+    shift = torch.empty_like(running_mean)
+    hip.call('tv_bn_eval_coeffs', cols, hip.ptr(running_mean), hip.ptr(running_var),
+             hip.ptr(_check(gamma, 'gamma')), hip.ptr(_check(beta, 'beta')), float(eps),
+             hip.ptr(scale), hip.ptr(shift))
+    return scale, shift
+
+
+def bn_lrelu(x, gamma, beta, running_mean, running_var, training: bool, eps: float,
+             momentum: float = 0.1, slope: float = 0.01, stats=None):
+    """BatchNorm over rows followed by LeakyReLU.  Training mode uses (and updates) batch
+    statistics; eval mode folds the running statistics into one affine pass."""
+    if training:
+        return _BNLReLUTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum,
+                                   slope, stats)
+    with torch.no_grad():
+        scale, shift = bn_eval_coeffs(running_mean, running_var, gamma, beta, eps)
+    return _AffineLReLU.apply(x, scale, shift, slope)
+
+
+# ---------------------------------------------------------------------------------------
+# GraphConv aggregation, readout, embedding
+# ---------------------------------------------------------------------------------------
+class _GraphSum(Function):
+    @staticmethod
+    def forward(ctx, x, graph: DeviceGraph, n_rep: int, scale_src: bool, scale_dst: bool):
+        x = _check(x, 'x')
+        rows, cols = x.shape
+        if rows != graph.num_rows * n_rep:
+            raise ValueError(f'graph_sum: {rows} rows do not match graph {graph.num_rows} x {n_rep}')
+        out = torch.empty_like(x)
+        hip.call('tv_graph_sum', graph.num_rows, n_rep, cols, hip.ptr(graph.indptr),
+                 hip.ptr(graph.indices), hip.ptr(x), int(scale_src), int(scale_dst), hip.ptr(out))
+        ctx.graph, ctx.n_rep, ctx.flags = graph, n_rep, (scale_src, scale_dst)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        # symmetric graph: the transpose aggregation is the same kernel, scalings swapped
+        dout = _check(dout, 'dout')
+        g = ctx.graph
+        dx = torch.empty_like(dout)
+        hip.call('tv_graph_sum', g.num_rows, ctx.n_rep, dout.shape[1], hip.ptr(g.indptr),
+                 hip.ptr(g.indices), hip.ptr(dout), int(ctx.flags[1]), int(ctx.flags[0]),
+                 hip.ptr(dx))
+        return dx, None, None, None, None
+
+
+def graph_sum(x, graph: DeviceGraph, n_rep: int = 1, scale_src: bool = True, scale_dst: bool = True):
+    return _GraphSum.apply(x, graph, n_rep, scale_src, scale_dst)
+
+
+class _SegmentMean(Function):
+    @staticmethod
+    def forward(ctx, x, node_offsets, graph_id):
+        x = _check(x, 'x')
+        batch = node_offsets.shape[0] - 1
+        out = torch.empty([batch, x.shape[1]], dtype=_f32, device=x.device)
+        hip.call('tv_segment_mean_fwd', batch, x.shape[1], hip.ptr(node_offsets), hip.ptr(x),
+                 hip.ptr(out))
+        ctx.save_for_backward(node_offsets, graph_id)
+        ctx.rows = x.shape[0]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        node_offsets, graph_id = ctx.saved_tensors
+        dout = _check(dout, 'dout')
+        dx = torch.empty([ctx.rows, dout.shape[1]], dtype=_f32, device=dout.device)
+        hip.call('tv_segment_mean_bwd', ctx.rows, dout.shape[1], hip.ptr(node_offsets),
+                 hip.ptr(graph_id), hip.ptr(dout), hip.ptr(dx))
+        return dx, None, None
+
+
+def segment_mean(x, node_offsets, graph_id):
+    return _SegmentMean.apply(x, node_offsets, graph_id)
+
+
+class _Embedding(Function):
+    @staticmethod
+    def forward(ctx, weight, ids, extra_cols: int):
+        weight = _check(weight, 'weight')
+        ids_flat = _check(ids.reshape(-1), 'ids', torch.int64)
+        rows, dim = ids_flat.shape[0], weight.shape[1]
+        ld = dim + extra_cols
+        out = torch.empty([rows, ld], dtype=_f32, device=weight.device)
+        hip.call('tv_embedding_fwd', rows, dim, weight.shape[0], hip.ptr(weight), hip.ptr(ids_flat),
+                 hip.ptr(out), ld, 0)
+        ctx.save_for_backward(ids_flat)
+        ctx.shape = weight.shape
+        ctx.ld = ld
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (ids_flat,) = ctx.saved_tensors
+        dout = _check(dout, 'dout')
+        v, dim = ctx.shape
+        dw = torch.empty([v, dim], dtype=_f32, device=dout.device)
+        hip.call('tv_embedding_bwd', ids_flat.shape[0], dim, v, hip.ptr(ids_flat), hip.ptr(dout),
+                 ctx.ld, 0, hip.ptr(dw))
+        return dw, None, None
+
+
+def embedding(weight, ids, extra_cols: int = 0):
+    """Row gather into the first `dim` columns of a `[rows, dim + extra_cols]` buffer (the
+    extra columns are left for the caller to fill, e.g. the latency feature)."""
+    return _Embedding.apply(weight, ids, extra_cols)
+
+
+class _LatDecInput(Function):
+    @staticmethod
+    def forward(ctx, z2, emb_weight, node_type_pad, n_samples: int):
+        z2 = _check(z2, 'z2')
+        emb_weight = _check(emb_weight, 'emb_weight')
+        batch, m = node_type_pad.shape
+        zdim, edim = z2.shape[-1], emb_weight.shape[1]
+        out = torch.empty([n_samples * batch * m, zdim + edim], dtype=_f32, device=z2.device)
+        hip.call('tv_latdec_input_fwd', n_samples, batch, m, zdim, edim, emb_weight.shape[0],
+                 hip.ptr(z2), hip.ptr(emb_weight), hip.ptr(node_type_pad), hip.ptr(out))
+        ctx.dims = (n_samples, batch, m, zdim, edim)
+        ctx.z2_shape = z2.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        k, b, m, zdim, edim = ctx.dims
+        dout = _check(dout, 'dout')
+        dz2 = torch.empty(ctx.z2_shape, dtype=_f32, device=dout.device)
+        hip.call('tv_latdec_input_bwd', k, b, m, zdim, edim, hip.ptr(dout), hip.ptr(dz2))
+        return dz2, None, None, None
+
+
+def latdec_input(z2, emb_weight, node_type_pad, n_samples: int):
+    """Rows `[z2 (broadcast over the M slots) || stop_grad(emb[node_type_pad])]`."""
+    return _LatDecInput.apply(z2, emb_weight, node_type_pad, n_samples)
+
+
+# ---------------------------------------------------------------------------------------
+# likelihoods
+# ---------------------------------------------------------------------------------------
+class _AdjLL(Function):
+    @staticmethod
+    def forward(ctx, h, adj, n_samples: int, biased: bool, alpha: float, log_thr: float):
+        h = _check(h, 'h')
+        adj = _check(adj, 'adj')
+        batch = adj.shape[0]
+        m, dim = h.shape[-2], h.shape[-1]
+        ll = torch.empty([n_samples * batch], dtype=_f32, device=h.device)
+        hip.call('tv_adj_bernoulli_ll_fwd', n_samples, batch, m, dim, hip.ptr(h), hip.ptr(adj),
+                 int(biased), float(alpha), float(log_thr), hip.ptr(ll))
+        ctx.save_for_backward(h, adj)
+        ctx.args = (n_samples, batch, m, dim, int(biased), float(alpha), float(log_thr))
+        return ll
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dll):
+        h, adj = ctx.saved_tensors
+        k, b, m, dim, biased, alpha, log_thr = ctx.args
+        dll = _check(dll, 'dll')
+        dh = torch.empty_like(h)
+        hip.call('tv_adj_bernoulli_ll_bwd', k, b, m, dim, hip.ptr(h), hip.ptr(adj), biased, alpha,
+                 log_thr, hip.ptr(dll), hip.ptr(dh))
+        return dh, None, None, None, None, None
+
+
+def adj_bernoulli_ll(h, adj, n_samples: int, biased: bool = False, alpha: float = 1.0,
+                     threshold: float = 0.5):
+    """h [K*B, M, D] (or [K,B,M,D]), adj [B,T] -> log p(adj) [K*B]."""
+    return _AdjLL.apply(h, adj, n_samples, biased, alpha, math.log(threshold))
+
+
+class _CategoricalLL(Function):
+    @staticmethod
+    def forward(ctx, logits, target, biased: bool, alpha: float, log_thr: float):
+        logits = _check(logits, 'logits')
+        target = _check(target.reshape(-1), 'target', torch.int64)
+        rows, classes = logits.shape
+        ll = torch.empty([rows], dtype=_f32, device=logits.device)
+        lse = torch.empty([rows], dtype=_f32, device=logits.device)
+        hip.call('tv_categorical_ll_fwd', rows, classes, target.shape[0], hip.ptr(logits),
+                 hip.ptr(target), int(biased), float(alpha), float(log_thr), hip.ptr(ll),
+                 hip.ptr(lse))
+        ctx.save_for_backward(logits, target, lse)
+        ctx.args = (int(biased), float(alpha), float(log_thr))
+        return ll
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dll):
+        logits, target, lse = ctx.saved_tensors
+        biased, alpha, log_thr = ctx.args
+        dll = _check(dll, 'dll')
+        dlogits = torch.empty_like(logits)
+        hip.call('tv_categorical_ll_bwd', logits.shape[0], logits.shape[1], target.shape[0],
+                 hip.ptr(logits), hip.ptr(target), biased, alpha, log_thr, hip.ptr(lse),
+                 hip.ptr(dll), hip.ptr(dlogits))
+        return dlogits, None, None, None, None
+
+
+def categorical_ll(logits, target, biased: bool = False, alpha: float = 1.0,
+                   threshold: float = 0.5):
+    """logits [rows, V]; target [target_rows] with rows % target_rows == 0 (the sample axis
+    of `logits` is outermost) -> log-prob per row."""
+    return _CategoricalLL.apply(logits, target, biased, alpha, math.log(threshold))
+
+
+def _bounds(lo, hi):
+    return (-math.inf if lo is None else float(lo), math.inf if hi is None else float(hi))
+
+
+class _NormalReparam(Function):
+    @staticmethod
+    def forward(ctx, mean, logstd_raw, eps, lo: float, hi: float):
+        mean, logstd_raw, eps = _check(mean, 'mean'), _check(logstd_raw, 'logstd'), _check(eps, 'eps')
+        batch, dim = mean.shape
+        k = eps.numel() // (batch * dim)
+        z = torch.empty_like(eps)
+        logq = torch.empty(eps.shape[:-1], dtype=_f32, device=mean.device)
+        logstd = torch.empty_like(mean)
+        hip.call('tv_normal_reparam_fwd', k, batch, dim, hip.ptr(mean), hip.ptr(logstd_raw), lo, hi,
+                 hip.ptr(eps), hip.ptr(z), hip.ptr(logq), hip.ptr(logstd))
+        ctx.save_for_backward(logstd_raw, eps)
+        ctx.args = (k, batch, dim, lo, hi)
+        ctx.mark_non_differentiable(logstd)
+        return z, logq, logstd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dlogq, _dlogstd):
+        logstd_raw, eps = ctx.saved_tensors
+        k, batch, dim, lo, hi = ctx.args
+        dz = _check(dz, 'dz') if dz is not None else None
+        dlogq = _check(dlogq, 'dlogq') if dlogq is not None else None
+        dmean = torch.empty_like(logstd_raw)
+        dls = torch.empty_like(logstd_raw)
+        hip.call('tv_normal_reparam_bwd', k, batch, dim, hip.ptr(logstd_raw), lo, hi, hip.ptr(eps),
+                 hip.ptr(dz), hip.ptr(dlogq), hip.ptr(dmean), hip.ptr(dls))
+        return dmean, dls, None, None, None
+
+
+def normal_reparam(mean, logstd_raw, eps, lo=None, hi=None):
+    """z = mean + exp(clamp(logstd)) * eps, log q(z) summed over the last axis.
+    mean/logstd_raw [B,D]; eps [B,D] or [K,B,D].  Returns (z, logq, clamped logstd)."""
+    lo, hi = _bounds(lo, hi)
+    return _NormalReparam.apply(mean, logstd_raw, eps, lo, hi)
+
+
+class _NormalLL(Function):
+    @staticmethod
+    def forward(ctx, x, mean, logstd_raw, lo: float, hi: float):
+        x, mean, logstd_raw = _check(x, 'x'), _check(mean, 'mean'), _check(logstd_raw, 'logstd')
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        ll = torch.empty(x.shape[:-1], dtype=_f32, device=x.device)
+        hip.call('tv_normal_ll_fwd', rows, dim, hip.ptr(x), hip.ptr(mean), hip.ptr(logstd_raw),
+                 lo, hi, hip.ptr(ll))
+        ctx.save_for_backward(x, mean, logstd_raw)
+        ctx.args = (rows, dim, lo, hi)
+        return ll
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dll):
+        x, mean, logstd_raw = ctx.saved_tensors
+        rows, dim, lo, hi = ctx.args
+        dll = _check(dll, 'dll')
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dmean = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        dls = torch.empty_like(x) if ctx.needs_input_grad[2] else None
+        hip.call('tv_normal_ll_bwd', rows, dim, hip.ptr(x), hip.ptr(mean), hip.ptr(logstd_raw),
+                 lo, hi, hip.ptr(dll), hip.ptr(dx), hip.ptr(dmean), hip.ptr(dls))
+        return dx, dmean, dls, None, None
+
+
+def normal_ll(x, mean, logstd_raw, lo=None, hi=None):
+    """sum over the last axis of Normal(x; mean, clamp(logstd_raw)); all three same shape."""
+    lo, hi = _bounds(lo, hi)
+    return _NormalLL.apply(x, mean, logstd_raw, lo, hi)
+
+
+LATENCY_MODES = {'normal': 0, 'safe': 1, 'biased': 2, 'anomaly': 3}
+
+
+class _LatencyLL(Function):
+    @staticmethod
+    def forward(ctx, feats, latency_pad, node_count, node_type_pad, std_limit, n_samples, cfg):
+        feats = _check(feats, 'feats')
+        batch, m = latency_pad.shape[0], latency_pad.shape[1]
+        ll = torch.empty([n_samples * batch], dtype=_f32, device=feats.device)
+        std_out = torch.empty([n_samples * batch * m], dtype=_f32, device=feats.device)
+        args = (n_samples, batch, m, hip.ptr(feats), hip.ptr(latency_pad), hip.ptr(node_count),
+                hip.ptr(node_type_pad), hip.ptr(std_limit)) + cfg
+        hip.call('tv_latency_ll_fwd', *args, hip.ptr(ll), hip.ptr(std_out))
+        ctx.save_for_backward(feats, latency_pad, node_count, node_type_pad,
+                              std_limit if std_limit is not None else feats.new_empty(0))
+        ctx.has_limit = std_limit is not None
+        ctx.n_samples, ctx.cfg = n_samples, cfg
+        ctx.mark_non_differentiable(std_out)
+        return ll, std_out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dll, _dstd):
+        feats, latency_pad, node_count, node_type_pad, std_limit = ctx.saved_tensors
+        if not ctx.has_limit:
+            std_limit = None
+        dll = _check(dll, 'dll')
+        batch, m = latency_pad.shape[0], latency_pad.shape[1]
+        dfeats = torch.empty_like(feats)
+        args = (ctx.n_samples, batch, m, hip.ptr(feats), hip.ptr(latency_pad), hip.ptr(node_count),
+                hip.ptr(node_type_pad), hip.ptr(std_limit)) + ctx.cfg
+        hip.call('tv_latency_ll_bwd', *args, hip.ptr(dll), hip.ptr(dfeats))
+        return dfeats, None, None, None, None, None, None
+
+
+def latency_ll(feats, latency_pad, node_count, node_type_pad, n_samples: int, *, mode: str,
+               std_threshold: float = 0.0, alpha: float = 1.0, bias_threshold: float = 0.5,
+               logstd_min=None, std_limit=None, use_mask: bool = True, weighted: bool = False):
+    """feats [K*B*M, 2] -> (log p(latency) [K*B], std [K*B*M])."""
+    cfg = (int(logstd_min is not None), float(logstd_min if logstd_min is not None else 0.0),
+           LATENCY_MODES[mode], float(std_threshold), float(alpha), math.log(bias_threshold),
+           int(use_mask), int(weighted))
+    lp = _check(latency_pad.reshape(latency_pad.shape[0], -1), 'latency_pad')
+    return _LatencyLL.apply(feats, lp, node_count, node_type_pad, std_limit, n_samples, cfg)
+
+
+def score_reduce(w: torch.Tensor, clip: Optional[float]):
+    """w = log_joint - latent_log_joint [K,B] -> (loss [B], nll [B]) (evaluation.py:141-148)."""
+    w = _check(w, 'w')
+    k, b = w.shape
+    loss = torch.empty([b], dtype=_f32, device=w.device)
+    nll = torch.empty([b], dtype=_f32, device=w.device)
+    hip.call('tv_score_reduce', k, b, hip.ptr(w), int(clip is not None),
+             float(clip if clip is not None else 0.0), hip.ptr(loss), hip.ptr(nll))
+    return loss, nll

@@ -1,0 +1,312 @@
+"""Training step, optimizer and loop of the accelerated path.
+
+Restates `tracegnn/models/trace_vae/train.py`:
+
+* `train_step` ELBO terms, KL beta, L2, unit-ball regularisers, NaN check      :213-277
+* two-phase schedule (all parameters, then `latency_vae.*` only with the rest
+  of the model in eval mode), LR annealing from the global epoch                :204-208, 374-383, 455-487
+* clip by global norm 10 + RMSprop / Adam (tensorkit `fit_model`)               :369-372, 417-426
+* `models/{epoch}.pt`, `models/final.pt` = `torch.save(vae.state_dict())`        :343-352
+
+MI355X-side design: all parameters live in ONE flat fp32 buffer (struct part first, the
+`latency_vae.*` part last, so the phase-2 subset is a contiguous suffix), gradients in a
+second one.  That makes the data-parallel exchange a single RCCL all-reduce over xGMI, and
+L2 / global-norm / clip / update three streaming kernels over the flat buffers
+(`csrc/optim.hip`).
+"""
+import json
+import math
+import os
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .batch import DeviceTraceStore, TraceGraphBatch
+from .config import ExpConfig, config_to_dict
+from .model import TraceVAE
+
+__all__ = ['NANLossError', 'FlatParameters', 'FlatOptimizer', 'compute_train_loss', 'Trainer',
+           'l2_parameter_names', 'learning_rate_for_epoch', 'save_model', 'StoreStream']
+
+
+class NANLossError(Exception):
+    def __init__(self, epoch):
+        super().__init__(epoch)
+
+    @property
+    def epoch(self) -> Optional[int]:
+        return self.args[0]
+
+    def __str__(self):
+        return f'NaN loss encountered at epoch {self.epoch}'
+
+
+def l2_parameter_names(all_names: Sequence[str], part_names: Sequence[str]) -> List[str]:
+    """Which parameters enter the L2 term.  The reference zips the *trained* parameter list
+    with the *full* name list (`zip(params, param_names)`, train.py:253-255), so in phase 2
+    the i-th trained parameter is filtered by the i-th name of the whole model.  Restated
+    as is (SURVEY.md appendix D lists the reference's quirks that affect parity)."""
+    return [p for p, n in zip(part_names, all_names) if 'bias' not in n]
+
+
+def learning_rate_for_epoch(cfg, epoch: int) -> float:
+    """train.py:374-380: lr = initial_lr * ratio ** (epoch // anneal_epochs), global epoch."""
+    return cfg.initial_lr * cfg.lr_anneal_ratio ** int(epoch // cfg.lr_anneal_epochs)
+
+
+class FlatParameters(object):
+    """Re-homes every parameter of `module` into one flat fp32 buffer (and `.grad` into a
+    second one).  Order: everything outside `latency_vae.` first, `latency_vae.` last."""
+
+    def __init__(self, module: torch.nn.Module, tail_prefix: str = 'latency_vae.'):
+        named = list(module.named_parameters())          # de-duplicated, registration order
+        self.all_names = [n for n, _ in named]
+        head = [(n, p) for n, p in named if not n.startswith(tail_prefix)]
+        tail = [(n, p) for n, p in named if n.startswith(tail_prefix)]
+        ordered = head + tail
+        device = ordered[0][1].device
+        sizes = [p.numel() for _, p in ordered]
+        # 64-element (256 B) aligned segments keep every parameter 16-B aligned for float4
+        starts, cur = [], 0
+        for s in sizes:
+            starts.append(cur)
+            cur += (s + 63) // 64 * 64
+        self.total = cur
+        self.flat = torch.zeros(cur, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(cur, dtype=torch.float32, device=device)
+        self.names = [n for n, _ in ordered]
+        self.slices: Dict[str, Tuple[int, int]] = {}
+        self.tail_start = cur
+        with torch.no_grad():
+            for (name, p), start, size in zip(ordered, starts, sizes):
+                view = self.flat[start:start + size].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[start:start + size].view(p.shape)
+                self.slices[name] = (start, start + size)
+                if name.startswith(tail_prefix) and start < self.tail_start:
+                    self.tail_start = start
+        self.params = dict(ordered)
+
+    def mask(self, names: Iterable[str]) -> torch.Tensor:
+        m = torch.zeros(self.total, dtype=torch.uint8)
+        for n in names:
+            a, b = self.slices[n]
+            m[a:b] = 1
+        return m.to(self.flat.device)
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+        for n, p in self.params.items():          # autograd may have replaced a view
+            a, b = self.slices[n]
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * a:
+                p.grad = self.grad[a:b].view(p.shape)
+
+
+class FlatOptimizer(object):
+    """RMSprop / Adam over a range of the flat buffer, with clip-by-global-norm
+    (`tv_sumsq_partial` -> `tv_sum_partials` -> `tv_optim_step`)."""
+
+    def __init__(self, flat: FlatParameters, kind: str = 'rmsprop', start: int = 0,
+                 end: Optional[int] = None, alpha: float = 0.99, betas=(0.9, 0.999),
+                 eps: float = 1e-8):
+        self.flat, self.kind = flat, kind.lower()
+        if self.kind not in ('rmsprop', 'adam'):
+            raise ValueError(f'unknown optimizer {kind!r}')
+        self.start, self.end = start, flat.total if end is None else end
+        n = self.end - self.start
+        dev = flat.flat.device
+        self.state1 = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.state2 = torch.zeros(n, dtype=torch.float32, device=dev) if self.kind == 'adam' else None
+        self.alpha, self.betas, self.eps = alpha, betas, eps
+        self.lr = 1e-3
+        self.steps = 0
+        self._partial = torch.empty(hip.query('tv_reduce_blocks', n), dtype=torch.float64, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def set_lr(self, lr: float) -> None:
+        self.lr = float(lr)
+
+    def step(self, global_clip_norm: Optional[float]) -> None:
+        n = self.end - self.start
+        p = self.flat.flat[self.start:self.end]
+        g = self.flat.grad[self.start:self.end]
+        norm_ptr = None
+        if global_clip_norm:
+            hip.call('tv_sumsq_partial', n, hip.ptr(g), None, hip.ptr(self._partial))
+            hip.call('tv_sum_partials', self._partial.shape[0], hip.ptr(self._partial), 1,
+                     hip.ptr(self.grad_norm))
+            norm_ptr = hip.ptr(self.grad_norm)
+        self.steps += 1
+        if self.kind == 'rmsprop':
+            kind, b1, b2 = 0, 0.0, self.alpha
+        else:
+            kind, (b1, b2) = 1, self.betas
+        hip.call('tv_optim_step', kind, n, hip.ptr(p), hip.ptr(g), hip.ptr(self.state1),
+                 hip.ptr(self.state2), norm_ptr, float(global_clip_norm or 0.0), self.lr,
+                 float(b1), float(b2), float(self.eps), self.steps)
+
+
+def _unit_ball(loss, t, reg):
+    """train.py:259-266 with get_moments(t, axis=[-1]) (tensor_utils.py:117-125)."""
+    if reg is not None:
+        m = t.mean(-1)
+        v = (t * t).mean(-1) - m * m
+        loss = loss + reg * ((m * m).mean() + ((v - 1) ** 2).mean())
+    return loss
+
+
+def compute_train_loss(chain, train_cfg, l2_value: Optional[torch.Tensor] = None,
+                       epoch: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """The loss of `train_step` (train.py:229-270) given the chain `q(G).chain(p, G=G)`."""
+    p_obs, p_latent, q_latent = [], [], []
+    for name in chain.p:
+        if name in chain.q:
+            q_latent.append(chain.q[name].log_prob())
+            p_latent.append(chain.p[name].log_prob())
+        else:
+            p_obs.append(chain.p[name].log_prob())
+    recons = sum(p_obs[1:], p_obs[0]).mean()
+    kl = (sum(q_latent[1:], q_latent[0]) - sum(p_latent[1:], p_latent[0])).mean()
+    beta = train_cfg.kl_beta
+    if train_cfg.warm_up_epochs and epoch is not None and epoch < train_cfg.warm_up_epochs:
+        beta = beta * (epoch / train_cfg.warm_up_epochs)
+    loss = beta * kl - recons
+    if train_cfg.l2_reg and l2_value is not None:
+        loss = loss + train_cfg.l2_reg * l2_value
+    loss = _unit_ball(loss, chain.q['z'].tensor, train_cfg.z_unit_ball_reg)
+    if 'z2' in chain.q:
+        loss = _unit_ball(loss, chain.q['z2'].tensor, train_cfg.z2_unit_ball_reg)
+    return {'loss': loss, 'recons': recons, 'kl': kl}
+
+
+class Trainer(object):
+    """One rank of the (optionally data-parallel) training job."""
+
+    def __init__(self, vae: TraceVAE, config: ExpConfig, latency_only: bool = False,
+                 process_group=None, world_size: Optional[int] = None):
+        self.vae, self.config = vae, config
+        self.train_cfg = config.train
+        self.flat = FlatParameters(vae)
+        self.pg = process_group
+        self.world_size = world_size if world_size is not None else (
+            dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1)
+        self.epoch = 1
+        self.set_phase(latency_only)
+
+    # -- phases ------------------------------------------------------------------------
+    def set_phase(self, latency_only: bool) -> None:
+        """Phase 1: every parameter; phase 2: `latency_vae.*` only (train.py:455-487)."""
+        self.latency_only = latency_only
+        f = self.flat
+        part = [n for n in f.all_names if n.startswith('latency_vae.')] if latency_only \
+            else list(f.all_names)
+        self.part_names = part
+        start = f.tail_start if latency_only else 0
+        self.optimizer = FlatOptimizer(f, self.train_cfg.optimizer, start, f.total)
+        self.optimizer.set_lr(learning_rate_for_epoch(self.train_cfg, self.epoch))
+        self.l2_names = l2_parameter_names(f.all_names, part)
+        self.l2_mask = f.mask(self.l2_names)
+        self._l2_partial = torch.empty(hip.query('tv_reduce_blocks', f.total), dtype=torch.float64,
+                                       device=f.flat.device)
+        self._l2_value = torch.zeros(1, dtype=torch.float32, device=f.flat.device)
+        self.apply_mode()
+
+    def apply_mode(self) -> None:
+        """on_train_epoch_begin (train.py:202-208)."""
+        if self.latency_only:
+            self.vae.eval()
+            self.vae.latency_vae.train()
+        else:
+            self.vae.train()
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+        self.optimizer.set_lr(learning_rate_for_epoch(self.train_cfg, epoch))
+
+    # -- one step ----------------------------------------------------------------------
+    def l2_value(self) -> torch.Tensor:
+        f = self.flat
+        hip.call('tv_sumsq_partial', f.total, hip.ptr(f.flat), hip.ptr(self.l2_mask),
+                 hip.ptr(self._l2_partial))
+        hip.call('tv_sum_partials', self._l2_partial.shape[0], hip.ptr(self._l2_partial), 0,
+                 hip.ptr(self._l2_value))
+        return self._l2_value[0]
+
+    def forward_loss(self, G: TraceGraphBatch, eps=None) -> Dict[str, torch.Tensor]:
+        chain = self.vae.q(G, eps=eps).chain(self.vae.p, G=G)
+        l2 = self.l2_value() if self.train_cfg.l2_reg else None
+        out = compute_train_loss(chain, self.train_cfg, l2, self.epoch)
+        out['chain'] = chain
+        return out
+
+    def step(self, G: TraceGraphBatch, eps=None, check_nan: bool = True) -> Dict[str, torch.Tensor]:
+        f = self.flat
+        f.zero_grad()
+        out = self.forward_loss(G, eps)
+        out['loss'].backward()
+        if self.train_cfg.l2_reg:
+            # d(l2_reg * sum p^2)/dp = 2 * l2_reg * p on the masked elements
+            hip.call('tv_axpy_masked', f.total, 2.0 * self.train_cfg.l2_reg, hip.ptr(f.flat),
+                     hip.ptr(self.l2_mask), hip.ptr(f.grad))
+        self.all_reduce_gradients()
+        if check_nan:
+            loss_val = float(out['loss'].item())          # host sync, like train.py:273
+            if math.isnan(loss_val):
+                raise NANLossError(self.epoch)
+        self.optimizer.step(self.train_cfg.global_clip_norm)
+        return {k: v.detach() for k, v in out.items() if k != 'chain'}
+
+    def all_reduce_gradients(self) -> None:
+        """One collective over the flat gradient bucket: sum over ranks, divide by world."""
+        if self.world_size <= 1:
+            return
+        g = self.flat.grad[self.optimizer.start:self.optimizer.end]
+        backend = dist.get_backend(self.pg)
+        if backend == 'nccl':   # RCCL over xGMI
+            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+            g.div_(self.world_size)
+
+
+def save_model(vae: TraceVAE, config: ExpConfig, out_dir: str, name: str = 'final') -> str:
+    """`results/train/config.json` + `results/train/models/{name}.pt` (train.py:343-352,
+    README.md:15, test_utils.py:22-33)."""
+    os.makedirs(os.path.join(out_dir, 'models'), exist_ok=True)
+    with open(os.path.join(out_dir, 'config.json'), 'w', encoding='utf-8') as f:
+        json.dump(config_to_dict(config), f, indent=2)
+    path = os.path.join(out_dir, 'models', f'{name}.pt')
+    torch.save({k: v.detach().cpu().clone() for k, v in vae.state_dict().items()}, path)
+    return path
+
+
+class StoreStream(object):
+    """Mini-batches of trace indices over a `DeviceTraceStore` (the role of
+    `TraceGraphDataStream`, dataset.py:92-133); rank r of W takes batches r, r+W, ..."""
+
+    def __init__(self, store: DeviceTraceStore, batch_size: int, shuffle: bool = False,
+                 seed: int = 0, rank: int = 0, world_size: int = 1,
+                 max_node_count: Optional[int] = None, skip_incomplete: bool = False):
+        self.store, self.batch_size, self.shuffle = store, batch_size, shuffle
+        self.rng = np.random.RandomState(seed)
+        self.rank, self.world_size = rank, world_size
+        self.max_node_count = max_node_count
+        self.skip_incomplete = skip_incomplete
+
+    @property
+    def batch_count(self) -> int:
+        n = len(self.store)
+        total = n // self.batch_size if self.skip_incomplete else -(-n // self.batch_size)
+        return len(range(self.rank, total, self.world_size))
+
+    def __iter__(self):
+        n = len(self.store)
+        order = self.rng.permutation(n) if self.shuffle else np.arange(n)
+        total = n // self.batch_size if self.skip_incomplete else -(-n // self.batch_size)
+        for i in range(self.rank, total, self.world_size):
+            ids = order[i * self.batch_size:(i + 1) * self.batch_size]
+            yield TraceGraphBatch.from_store(self.store, ids, self.max_node_count)
