@@ -76,15 +76,23 @@ def test_train_step_loss_and_gradients(device, V, M, width, layers, batch):
     # gradients of every parameter (before the L2 term, which the trainer adds separately:
     # remove it from the oracle gradient)
     l2_names = set(trainer.l2_names)
-    worst = 0.0
+    wants = {}
     for n, p in vae.named_parameters():
         want = P[n].grad
         if n in l2_names:
             want = want - 2.0 * cfg.train.l2_reg * P[n].detach()
-        scale = max(float(want.abs().max()), 1e-6)
+        wants[n] = want
+    gmax = max(float(w.abs().max()) for w in wants.values())
+    bad = []
+    for n, p in vae.named_parameters():
+        want = wants[n]
+        # parameters whose true gradient is zero (a GAT bias in front of a training-mode
+        # BatchNorm) carry only rounding noise: measure those against the global scale
+        scale = max(float(want.abs().max()), 1e-4 * gmax)
         err = float((p.grad.double().cpu() - want).abs().max()) / scale
-        worst = max(worst, err)
-        assert err < 20 * PATH_TOL, (n, err)
+        if not err < 20 * PATH_TOL:
+            bad.append((n, err, float(want.abs().max())))
+    assert not bad, bad
     # BatchNorm running statistics moved the same way
     sd = vae.state_dict()
     for k, v in buf.items():
@@ -159,11 +167,21 @@ def test_trainer_step_matches_oracle_update(device):
     G = TraceGraphBatch.from_store(store, np.arange(B), M)
     out = trainer.step(G, eps={'z': eps_z, 'z2': eps_z2})
     assert rel_err(out['loss'], ref['loss']) < PATH_TOL
+    gmax = max(float(P[n].grad.abs().max()) for n in names)
+    bad = []
     for n, p in vae.named_parameters():
+        if float(P[n].grad.abs().max()) < 1e-5 * gmax:
+            continue     # zero-gradient parameters: RMSprop turns rounding noise into +-lr steps
         want_delta = P[n].detach() - before[n]
         got_delta = p.detach().double().cpu() - before[n]
-        scale = max(float(want_delta.abs().max()), 1e-9)
-        assert float((got_delta - want_delta).abs().max()) / scale < 5e-3, n
+        # RMSprop's first step is ~ lr * sign(g) * 10 wherever |g| >> eps; compare where the
+        # gradient is clearly non-zero
+        sel = P[n].grad.abs() > 1e-4 * gmax
+        if sel.any():
+            err = float((got_delta - want_delta)[sel].abs().max() / want_delta[sel].abs().max())
+            if not err < 5e-3:
+                bad.append((n, err))
+    assert not bad, bad
 
 
 def test_phase2_latency_only(device):

@@ -68,6 +68,12 @@ class DeviceTraceStore(object):
         self.lat_mean = torch.as_tensor(mean).to(self.device)
         self.lat_std = torch.as_tensor(std).to(self.device)
         self.labels = flat.labels
+        # node types / latency ranges are checked once here; a batch only needs the kernel's
+        # status word (a host sync) when the store is known to hold a problem
+        used = np.unique(flat.node_type) if len(flat.node_type) else np.zeros(0, np.int64)
+        in_range = (used >= 0) & (used < self.num_operations)
+        self.needs_status_check = bool((~in_range).any()) or bool(
+            np.isnan(mean[used[in_range]]).any() or np.isnan(std[used[in_range]]).any())
 
     def __len__(self) -> int:
         return len(self.node_counts_host)
@@ -138,6 +144,13 @@ def build_device_batch(store: DeviceTraceStore, trace_ids: np.ndarray,
     out.graph_id = i64(n)
     out.status = torch.zeros([1], dtype=torch.int32, device=dev)
     p = hip.ptr
+    if b == 0:
+        # nothing to launch: the only defined entries are the two CSC terminators
+        enc_indptr.zero_()
+        dec_indptr.zero_()
+        out.enc = DeviceGraph(enc_indptr, enc_indices, enc_eids, enc_rev, enc_src, enc_dst)
+        out.dec = DeviceGraph(dec_indptr, dec_indices, dec_eids, dec_rev, dec_src, dec_dst)
+        return out
     hip.call('tv_batch_build', b, m, n, store.num_operations, p(d_off), p(d_nstart), p(d_estart),
              p(store.u), p(store.v), p(store.node_type), p(store.avg_latency),
              p(store.min_latency), p(store.max_latency), p(store.lat_mean), p(store.lat_std),
@@ -147,7 +160,7 @@ def build_device_batch(store: DeviceTraceStore, trace_ids: np.ndarray,
              p(out.node_type), p(out.latency), p(out.graph_id), p(out.status))
     out.enc = DeviceGraph(enc_indptr, enc_indices, enc_eids, enc_rev, enc_src, enc_dst)
     out.dec = DeviceGraph(dec_indptr, dec_indices, dec_eids, dec_rev, dec_src, dec_dst)
-    if check:
+    if check and store.needs_status_check:
         out.check_status()
     return out
 

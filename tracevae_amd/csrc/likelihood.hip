@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256) void latency_ll_kernel(LatArgs a, float *__res
         if (a.mode == 2 && fabsf(x - mu) > a.thr * sd) { lp *= a.alpha; scale = a.alpha; }
       }
       if (!BWD) {
-        if (live) acc += lp * w;
+        // MaskedDistribution multiplies: log_prob * mask * weight (distributions.py:74-78),
+        // so a non-finite log_prob of a masked slot still poisons the sum like it does there
+        acc += lp * (live ? 1.0f : 0.0f) * w;
       } else {
         const float g = live ? g0 * scale : 0.f;
         dfeats[2 * r] = g * diff * prec;

@@ -241,7 +241,7 @@ def rowdot(x, w):
 class _GATConv(Function):
     @staticmethod
     def forward(ctx, ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int, want_stats: bool,
-                ep_scale, ep_shift, ep_slope: float):
+                ep_scale, ep_shift, ep_slope: float, need_grad: bool):
         ft = _check(ft, 'ft')
         heads, feats = int(attn_l.shape[-2]), int(attn_l.shape[-1])
         rows = ft.shape[0]
@@ -255,7 +255,6 @@ class _GATConv(Function):
         er = torch.empty([rows, heads], dtype=_f32, device=dev)
         hip.call('tv_gat_scores', rows, heads, feats, hip.ptr(ft), hip.ptr(al), hip.ptr(ar),
                  hip.ptr(el), hip.ptr(er))
-        need_grad = any(ctx.needs_input_grad[:4])
         if need_grad and n_rep != 1:
             raise ValueError('gat_conv: gradients are only available for a single graph replica')
         out = torch.empty([rows, heads * feats], dtype=_f32, device=dev)
@@ -309,15 +308,19 @@ class _GATConv(Function):
                      hip.ptr(dout), hip.ptr(dft), hip.ptr(dal), hip.ptr(dar), hip.ptr(dbias),
                      hip.ptr(ws), wsb)
         return (dft, dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape), dbias,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def gat_conv(ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int = 1,
              want_stats: bool = False, ep_scale=None, ep_shift=None, ep_slope: float = 0.01):
     """GATConv message passing after the fc projection.  Returns `(out, stats_partial)`;
     `stats_partial` is an empty tensor unless `want_stats`."""
+    # (grad mode is always off inside Function.forward, so decide here whether the
+    # attention coefficients must be kept for a backward pass)
+    need_grad = torch.is_grad_enabled() and any(
+        t.requires_grad for t in (ft, attn_l, attn_r, bias))
     return _GATConv.apply(ft, attn_l, attn_r, bias, graph, n_rep, want_stats, ep_scale, ep_shift,
-                          ep_slope)
+                          ep_slope, need_grad)
 
 
 # ---------------------------------------------------------------------------------------
