@@ -391,7 +391,7 @@ def test_latency_ll(device, mode, weighted, use_limit):
         feats[:, 1] = feats[:, 1].abs() + 0.5
     node_count = torch.randint(2, M + 1, (B,), generator=torch.Generator().manual_seed(3))
     ntp = torch.randint(0, V, (B, M), generator=torch.Generator().manual_seed(4))
-    std_limit = (_rand(V, seed=5).abs() + 0.05) if use_limit else None
+    std_limit = (_rand(V, seed=5).abs() + (2.0 if mode == 'anomaly' else 0.05)) if use_limit else None
     thr, alpha = (6.0, 1.0) if mode == 'safe' else (1.5, float(M))
 
     fr = feats.clone().requires_grad_(True)
