@@ -2,6 +2,7 @@
 // at most 8 columns (the 1000->2 latency head) and column sums (bias gradients).
 // Fixed-order two-stage reductions, no atomics.
 #include "tv_common.h"
+#include "tv_slots.h"
 
 namespace {
 
@@ -89,11 +90,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t rows, int64
 __global__ __launch_bounds__(256) void sum_slots_kernel(int64_t nblk, int64_t n,
                                                         const float *__restrict__ partial,
                                                         float *__restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double acc = 0.0;
-  for (int64_t b = 0; b < nblk; ++b) acc += (double)partial[b * n + i];
-  out[i] = (float)acc;
+  const int64_t i = (int64_t)blockIdx.x * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
+  double tot[1];
+  tv_slot_sums<1>(partial, nblk, n, 0, i, i < n, tot);
+  if (threadIdx.x < TV_SLOT_COLS && i < n) out[i] = (float)tot[0];
 }
 
 }  // namespace
@@ -140,7 +140,7 @@ extern "C" int tv_rowdot_bwd(int64_t rows, int64_t k, int64_t n, const float *x,
   hipLaunchKernelGGL(rowdot_bwd_dw_kernel, dim3((unsigned)tv_cdiv(k, 256), (unsigned)nblk), dim3(256),
                      0, s, rows, k, (int)n, x, row_scale, dout, (float *)workspace);
   TV_LAUNCH_CHECK("tv_rowdot_bwd(dw)");
-  hipLaunchKernelGGL(sum_slots_kernel, dim3((unsigned)tv_cdiv(k * n, 256)), dim3(256), 0, s, nblk,
+  hipLaunchKernelGGL(sum_slots_kernel, dim3(tv_slot_grid(k * n)), dim3(256), 0, s, nblk,
                      k * n, (const float *)workspace, dw);
   TV_LAUNCH_CHECK("tv_rowdot_bwd(reduce)");
   return TV_OK;
@@ -165,7 +165,7 @@ extern "C" int tv_colsum(int64_t rows, int64_t cols, const float *x, int64_t ldx
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)tv_cdiv(cols, 256), (unsigned)nblk),
                      dim3(256), 0, s, rows, cols, ldx, x, (float *)workspace);
   TV_LAUNCH_CHECK("tv_colsum(partial)");
-  hipLaunchKernelGGL(sum_slots_kernel, dim3((unsigned)tv_cdiv(cols, 256)), dim3(256), 0, s, nblk,
+  hipLaunchKernelGGL(sum_slots_kernel, dim3(tv_slot_grid(cols)), dim3(256), 0, s, nblk,
                      cols, (const float *)workspace, out);
   TV_LAUNCH_CHECK("tv_colsum(reduce)");
   return TV_OK;

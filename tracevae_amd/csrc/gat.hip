@@ -12,6 +12,7 @@
 // HBM-bound.  Algorithmic bytes, forward, per destination row with d in-edges:
 //   4*HF*d (ft gathers) + 4*HF (out) + 8*H*(d+1) (scores) + 8*d (indices) + 4*H*d (alpha).
 #include "tv_common.h"
+#include "tv_slots.h"
 
 namespace {
 
@@ -452,18 +453,18 @@ __global__ __launch_bounds__(512) void gat_bwd_node_kernel(AggArgs a) {
   block_col_reduce<3, CH>(lds, v, c4, a.partial + (int64_t)blockIdx.x * 3 * HF);
 }
 
-// out[s*C + c] = sum_b partial[b][s][c] in workgroup order (double accumulation)
+// out[s*C + c] = sum_b partial[b][s][c] in workgroup order (float64 accumulation)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t nblk, int64_t sc,
                                                               const float *__restrict__ partial,
                                                               float *o0, float *o1, float *o2,
                                                               int64_t C) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= sc) return;
-  double acc = 0.0;
-  for (int64_t b = 0; b < nblk; ++b) acc += (double)partial[b * sc + i];
+  const int64_t i = (int64_t)blockIdx.x * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
+  double tot[1];
+  tv_slot_sums<1>(partial, nblk, sc, 0, i, i < sc, tot);
+  if (threadIdx.x >= TV_SLOT_COLS || i >= sc) return;
   const int64_t s = i / C, c = i - s * C;
   float *o = (s == 0) ? o0 : (s == 1 ? o1 : o2);
-  if (o) o[c] = (float)acc;
+  if (o) o[c] = (float)tot[0];
 }
 
 int check_shape(const char *name, int64_t rows_per_rep, int64_t n_rep, int64_t heads,
@@ -602,7 +603,7 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
     else hipLaunchKernelGGL((gat_bwd_node_kernel<4>), grid, block, ldsb, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(node)");
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)tv_cdiv(3 * HF, 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(tv_slot_grid(3 * HF)), dim3(256), 0, s,
                      nblk, 3 * HF, a.partial, dattn_l, dattn_r, dbias, HF);
   TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(reduce)");
   return TV_OK;

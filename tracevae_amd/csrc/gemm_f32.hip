@@ -36,70 +36,95 @@ struct GemmArgs {
   int64_t splits, k_chunk;   // k_chunk is a multiple of BK
   float *slabs;              // [splits, M, N] when splits > 1
   int accumulate;
-  int a_vec, b_vec;          // 16-byte loads allowed for the operand
+  int a_vec, b_vec;          // 16-byte loads allowed for the operand (host-side dispatch)
 };
 
-__device__ __forceinline__ float4 load4_guard(const float *base, int64_t row, int64_t nrows,
-                                              int64_t col, int64_t ncols, int64_t ld, int vec_ok) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < nrows && col < ncols) {
-    const float *p = base + row * ld + col;
-    if (vec_ok && col + 3 < ncols) {
-      v = *reinterpret_cast<const float4 *>(p);
+// Tile staging.  One operand tile is 128 (x) by 32 (k) floats, 16 floats per thread.
+// Every load is unconditional from a clamped (always valid) address and zeroed by a
+// select afterwards, so the main loop has no divergent branches.
+//   VEC  (16-B loads; needs ld % 4 == 0, 16-B aligned base, contiguous extent % 4 == 0)
+//     [X][K] storage: float4 = 4 consecutive k of row x = (t>>3) + 32*it, k = (t&7)*4
+//     [K][X] storage: float4 = 4 consecutive x of row k = (t>>5) + 8*it,  x = (t&31)*4
+//   scalar (any ld / alignment): element e = t + 256*i
+//     [X][K] storage: k = e & 31,  x = e >> 5     (32 consecutive floats of a row)
+//     [K][X] storage: x = e & 127, k = e >> 7     (128 consecutive floats of a k-row)
+template <bool KMAJOR, bool VEC>
+struct Stager {
+  float r[16];
+  unsigned okmask;   // validity of the staged loads; applied when the tile is written to LDS,
+                     // so that nothing consumes a load result before the MFMA phase
+  const float *base;
+  int64_t ld, x0, xlim;
+  int t;
+
+  __device__ __forceinline__ void init(const float *b, int64_t ld_, int64_t x0_, int64_t xlim_,
+                                       int t_) {
+    base = b; ld = ld_; x0 = x0_; xlim = xlim_; t = t_;
+  }
+
+  __device__ __forceinline__ void load(int64_t k0, int64_t klim) {
+    okmask = 0;
+    if (VEC) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        int64_t x, k;
+        if (!KMAJOR) { x = x0 + (t >> 3) + 32 * it; k = k0 + (t & 7) * 4; }
+        else         { x = x0 + (t & 31) * 4;       k = k0 + (t >> 5) + 8 * it; }
+        const bool ok = (x < xlim) && (k < klim);
+        const int64_t xc = ok ? x : 0, kc = ok ? k : 0;
+        const float *p = KMAJOR ? (base + kc * ld + xc) : (base + xc * ld + kc);
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        r[4 * it + 0] = v.x; r[4 * it + 1] = v.y; r[4 * it + 2] = v.z; r[4 * it + 3] = v.w;
+        okmask |= ok ? (1u << it) : 0u;
+      }
     } else {
-      v.x = p[0];
-      if (col + 1 < ncols) v.y = p[1];
-      if (col + 2 < ncols) v.z = p[2];
-      if (col + 3 < ncols) v.w = p[3];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int64_t x, k;
+        if (!KMAJOR) { k = k0 + (t & 31);  x = x0 + (t >> 5) + 8 * i; }
+        else         { x = x0 + (t & 127); k = k0 + (t >> 7) + 2 * i; }
+        const bool ok = (x < xlim) && (k < klim);
+        const int64_t xc = ok ? x : 0, kc = ok ? k : 0;
+        r[i] = KMAJOR ? base[kc * ld + xc] : base[xc * ld + kc];
+        okmask |= ok ? (1u << i) : 0u;
+      }
     }
   }
-  return v;
-}
 
-// Operand stored [X][K] (K contiguous): thread t loads float4 k-quads of 4 rows.
-//   tile element (x, k): x = (t>>3) + 32*it, k = (t&7)*4 + j
-// Operand stored [K][X] (X contiguous): thread t loads float4 x-quads of 4 k-rows.
-//   tile element (x, k): x = (t&31)*4 + j, k = (t>>5) + 8*it
-template <bool KMAJOR>
-__device__ __forceinline__ void load_tile(float4 (&r)[4], const float *base, int64_t x0,
-                                          int64_t xlim, int64_t k0, int64_t klim, int64_t ld,
-                                          int vec_ok, int t) {
-  if (!KMAJOR) {
-    const int64_t k = k0 + (t & 7) * 4;
+  __device__ __forceinline__ void store(float *s) const {
+    if (VEC) {
+      if (!KMAJOR) {
+        const int k = (t & 7) * 4;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      r[it] = load4_guard(base, x0 + (t >> 3) + 32 * it, xlim, k, klim, ld, vec_ok);
-  } else {
-    const int64_t x = x0 + (t & 31) * 4;
+        for (int it = 0; it < 4; ++it) {
+          const int x = (t >> 3) + 32 * it;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      r[it] = load4_guard(base, k0 + (t >> 5) + 8 * it, klim, x, xlim, ld, vec_ok);
-  }
-}
-
-template <bool KMAJOR>
-__device__ __forceinline__ void store_tile(const float4 (&r)[4], float *s, int t) {
-  if (!KMAJOR) {
-    const int k = (t & 7) * 4;
+          for (int j = 0; j < 4; ++j)
+            s[(k + j) * LDS_STRIDE + x] = ((okmask >> it) & 1u) ? r[4 * it + j] : 0.f;
+        }
+      } else {
+        const int x = (t & 31) * 4;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int x = (t >> 3) + 32 * it;
-      s[(k + 0) * LDS_STRIDE + x] = r[it].x;
-      s[(k + 1) * LDS_STRIDE + x] = r[it].y;
-      s[(k + 2) * LDS_STRIDE + x] = r[it].z;
-      s[(k + 3) * LDS_STRIDE + x] = r[it].w;
-    }
-  } else {
-    const int x = (t & 31) * 4;
+        for (int it = 0; it < 4; ++it) {
+          const int k = (t >> 5) + 8 * it;
+          const bool ok = (okmask >> it) & 1u;
+          *reinterpret_cast<float4 *>(&s[k * LDS_STRIDE + x]) =
+              make_float4(ok ? r[4 * it] : 0.f, ok ? r[4 * it + 1] : 0.f,
+                          ok ? r[4 * it + 2] : 0.f, ok ? r[4 * it + 3] : 0.f);
+        }
+      }
+    } else {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int k = (t >> 5) + 8 * it;
-      *reinterpret_cast<float4 *>(&s[k * LDS_STRIDE + x]) = r[it];
+      for (int i = 0; i < 16; ++i) {
+        const float v = ((okmask >> i) & 1u) ? r[i] : 0.f;
+        if (!KMAJOR) s[(t & 31) * LDS_STRIDE + (t >> 5) + 8 * i] = v;
+        else         s[((t >> 7) + 2 * i) * LDS_STRIDE + (t & 127)] = v;
+      }
     }
   }
-}
+};
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <bool A_KMAJOR, bool B_KMAJOR, bool A_VEC, bool B_VEC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __align__(16) float smem[4 * TILE_FLOATS];  // A0 A1 B0 B1
   const int t = threadIdx.x;
@@ -130,14 +155,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rb[4];
+  Stager<A_KMAJOR, A_VEC> sa;
+  Stager<B_KMAJOR, B_VEC> sb;
+  sa.init(g.A, g.lda, m0, g.M, t);
+  sb.init(g.B, g.ldb, n0, g.N, t);
   float *As = smem, *Bs = smem + 2 * TILE_FLOATS;
 
   if (nt > 0) {
-    load_tile<A_KMAJOR>(ra, g.A, m0, g.M, kbeg, kend, g.lda, g.a_vec, t);
-    load_tile<B_KMAJOR>(rb, g.B, n0, g.N, kbeg, kend, g.ldb, g.b_vec, t);
-    store_tile<A_KMAJOR>(ra, As, t);
-    store_tile<B_KMAJOR>(rb, Bs, t);
+    sa.load(kbeg, kend);
+    sb.load(kbeg, kend);
+    sa.store(As);
+    sb.store(Bs);
   }
   __syncthreads();
 
@@ -148,25 +176,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const bool more = (it + 1 < nt);
     if (more) {
       const int64_t k0 = kbeg + (it + 1) * BK;
-      load_tile<A_KMAJOR>(ra, g.A, m0, g.M, k0, kend, g.lda, g.a_vec, t);
-      load_tile<B_KMAJOR>(rb, g.B, n0, g.N, k0, kend, g.ldb, g.b_vec, t);
+      sa.load(k0, kend);
+      sb.load(k0, kend);
     }
-    const float *as = As + cur * TILE_FLOATS + wm * 64 + xl;
-    const float *bs = Bs + cur * TILE_FLOATS + wn * 64 + xl;
+    const float *as = As + cur * TILE_FLOATS + wm * 64 + xl + kh * LDS_STRIDE;
+    const float *bs = Bs + cur * TILE_FLOATS + wn * 64 + xl + kh * LDS_STRIDE;
+    // operand fragments are read one k-step ahead of the MFMAs that use them
+    float fa[2][2], fb[2][2];
+    fa[0][0] = as[0]; fa[0][1] = as[32]; fb[0][0] = bs[0]; fb[0][1] = bs[32];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = as[(kk + kh) * LDS_STRIDE];
-      const float a1 = as[(kk + kh) * LDS_STRIDE + 32];
-      const float b0 = bs[(kk + kh) * LDS_STRIDE];
-      const float b1 = bs[(kk + kh) * LDS_STRIDE + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const int c = (kk >> 1) & 1, nx = c ^ 1;
+      if (kk + 2 < BK) {
+        fa[nx][0] = as[(kk + 2) * LDS_STRIDE];
+        fa[nx][1] = as[(kk + 2) * LDS_STRIDE + 32];
+        fb[nx][0] = bs[(kk + 2) * LDS_STRIDE];
+        fb[nx][1] = bs[(kk + 2) * LDS_STRIDE + 32];
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
+      // pin the emitted order: the LDS reads of the next k-step go out before this step's
+      // four MFMAs, so their latency hides under 256 cycles of matrix work
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
     if (more) {
-      store_tile<A_KMAJOR>(ra, As + (cur ^ 1) * TILE_FLOATS, t);
-      store_tile<B_KMAJOR>(rb, Bs + (cur ^ 1) * TILE_FLOATS, t);
+      sa.store(As + (cur ^ 1) * TILE_FLOATS);
+      sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
     }
     __syncthreads();
   }
@@ -175,24 +213,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const bool split = g.splits > 1;
   float *out = split ? (g.slabs + sp * g.M * g.N) : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
+  const bool plain = split || (!g.row_scale && !g.accumulate);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t col = n0 + wn * 64 + j * 32 + xl;
-      if (col >= g.N) continue;
-      const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+      const bool colok = col < g.N;
+      const float bv = (!split && g.bias && colok) ? g.bias[col] : 0.f;
+      const int64_t rbase = m0 + wm * 64 + i * 32 + 4 * kh;
+      if (plain) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row >= g.M) continue;
-        float v = acc[i][j][r];
-        if (!split) {
-          if (g.row_scale) v *= g.row_scale[row];
-          v += bv;
-          if (g.accumulate) v += out[row * ldo + col];
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+          if (colok && row < g.M) out[row * ldo + col] = acc[i][j][r] + bv;
         }
-        out[row * ldo + col] = v;
+      } else {
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+          if (colok && row < g.M) {
+            float v = acc[i][j][r];
+            if (g.row_scale) v *= g.row_scale[row];
+            v += bv;
+            if (g.accumulate) v += out[row * ldo + col];
+            out[row * ldo + col] = v;
+          }
+        }
       }
     }
   }
@@ -255,8 +301,9 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
   g.splits = tv_cdiv(k, g.k_chunk);
   g.slabs = nullptr;
   g.accumulate = accumulate;
-  g.a_vec = (lda % 4 == 0) && (((uintptr_t)a & 15) == 0);
-  g.b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0);
+  // 16-B loads need aligned rows and a contiguous extent that is a multiple of 4
+  g.a_vec = (lda % 4 == 0) && (((uintptr_t)a & 15) == 0) && ((trans_a ? m : k) % 4 == 0);
+  g.b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0) && ((trans_b ? k : n) % 4 == 0);
   if (g.splits > 1) {
     const int64_t need = g.splits * m * n * (int64_t)sizeof(float);
     if (!workspace || workspace_bytes < need) {
@@ -270,11 +317,21 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
   const int64_t nwg = g.tiles_m * g.tiles_n * g.splits;
   TV_REQUIRE(nwg < (1ll << 31), "tv_gemm_f32: grid too large");
   const dim3 grid((unsigned)nwg), block(256);
-  const bool ak = trans_a != 0, bk = trans_b == 0;
-  if (!ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, g);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, g);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, g);
+  const int variant = (trans_a != 0 ? 8 : 0) | (trans_b == 0 ? 4 : 0) | (g.a_vec ? 2 : 0) |
+                      (g.b_vec ? 1 : 0);
+#define TV_GEMM_CASE(V, AK, BK_, AV, BV)                                                        \
+  case V: hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, AV, BV>), grid, block, 0, s, g); break;
+  switch (variant) {
+    TV_GEMM_CASE(0, false, false, false, false) TV_GEMM_CASE(1, false, false, false, true)
+    TV_GEMM_CASE(2, false, false, true, false)  TV_GEMM_CASE(3, false, false, true, true)
+    TV_GEMM_CASE(4, false, true, false, false)  TV_GEMM_CASE(5, false, true, false, true)
+    TV_GEMM_CASE(6, false, true, true, false)   TV_GEMM_CASE(7, false, true, true, true)
+    TV_GEMM_CASE(8, true, false, false, false)  TV_GEMM_CASE(9, true, false, false, true)
+    TV_GEMM_CASE(10, true, false, true, false)  TV_GEMM_CASE(11, true, false, true, true)
+    TV_GEMM_CASE(12, true, true, false, false)  TV_GEMM_CASE(13, true, true, false, true)
+    TV_GEMM_CASE(14, true, true, true, false)   TV_GEMM_CASE(15, true, true, true, true)
+  }
+#undef TV_GEMM_CASE
   TV_LAUNCH_CHECK("tv_gemm_f32");
   if (g.splits > 1) {
     int64_t blocks = tv_cdiv(m * n, 256);

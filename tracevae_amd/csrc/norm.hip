@@ -6,6 +6,7 @@
 // Algorithmic bytes per row of C floats: stats 4C (read), apply 8C (read+write),
 // backward 8C (reduce: x, dy) + 12C (apply: x, dy, dx).
 #include "tv_common.h"
+#include "tv_slots.h"
 
 namespace {
 
@@ -31,15 +32,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int64_t C, int64_t nbl
                                                           float *mean, float *rstd,
                                                           float *running_mean,
                                                           float *running_var) {
-  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (col >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int64_t b = 0; b < nblk; ++b) {
-    s += (double)partial[(b * 2 + 0) * C + col];
-    q += (double)partial[(b * 2 + 1) * C + col];
-  }
-  const double m = s / count;
-  double var = q / count - m * m;
+  const int64_t col = (int64_t)blockIdx.x * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
+  double tot[2];
+  tv_slot_sums<2>(partial, nblk, 2 * C, C, col, col < C, tot);
+  if (threadIdx.x >= TV_SLOT_COLS || col >= C) return;
+  const double m = tot[0] / count;
+  double var = tot[1] / count - m * m;
   if (var < 0.0) var = 0.0;
   mean[col] = (float)m;
   rstd[col] = (float)(1.0 / sqrt(var + (double)eps));
@@ -133,17 +131,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int64_t C, int64_t
                                                               const float *__restrict__ partial,
                                                               float *sums, float *dgamma,
                                                               float *dbeta) {
-  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (col >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int64_t b = 0; b < nblk; ++b) {
-    s1 += (double)partial[(b * 2 + 0) * C + col];
-    s2 += (double)partial[(b * 2 + 1) * C + col];
-  }
-  sums[col] = (float)s1;
-  sums[C + col] = (float)s2;
-  dbeta[col] = (float)s1;
-  dgamma[col] = (float)s2;
+  const int64_t col = (int64_t)blockIdx.x * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
+  double tot[2];
+  tv_slot_sums<2>(partial, nblk, 2 * C, C, col, col < C, tot);
+  if (threadIdx.x >= TV_SLOT_COLS || col >= C) return;
+  sums[col] = (float)tot[0];
+  sums[C + col] = (float)tot[1];
+  dbeta[col] = (float)tot[0];
+  dgamma[col] = (float)tot[1];
 }
 
 // backward, stage 2: dx = gamma*rstd*(dyl - mean(dyl) - xhat*mean(dyl*xhat))
@@ -206,7 +201,7 @@ extern "C" int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, 
   TV_REQUIRE(partial && mean && rstd, "tv_bn_finalize: null pointer");
   TV_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
              "tv_bn_finalize: running_mean and running_var go together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)tv_cdiv(cols, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(tv_slot_grid(cols)), dim3(256), 0,
                      (hipStream_t)stream, cols, nblk, partial, (double)count, eps, momentum, mean,
                      rstd, running_mean, running_var);
   TV_LAUNCH_CHECK("tv_bn_finalize");
@@ -284,7 +279,7 @@ extern "C" int tv_bn_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)tv_cdiv(cols, 256), (unsigned)nblk),
                      dim3(256), 0, s, rows, cols, x, dy, mean, rstd, gamma, beta, slope, partial);
   TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(reduce)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)tv_cdiv(cols, 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tv_slot_grid(cols)), dim3(256), 0, s,
                      cols, nblk, partial, sums, dgamma, dbeta);
   TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(finalize)");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, s, rows,

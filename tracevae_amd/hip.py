@@ -22,7 +22,8 @@ class HipLibraryError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, 'csrc', _LIB_NAME)
+    # TRACEVAE_HIP_LIB selects another build of the same library (kernel A/B experiments)
+    return os.environ.get('TRACEVAE_HIP_LIB') or os.path.join(_HERE, 'csrc', _LIB_NAME)
 
 
 def header_path() -> str:
