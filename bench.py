@@ -29,6 +29,22 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, fp32 matrix (dense)
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per GEMM launch of the default workload, from the committed --pmc passes
+# (tools/summarize_profile.py traffic; FETCH_SIZE x2 + WRITE_SIZE, separate passes)
+TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r01b_hbm_traffic.json')
+
+
+def measured_traffic(args):
+    """PMC counters cannot be read from inside the timed run; the figure comes from the
+    committed rocprofv3 --pmc passes over this same command, and only for the workload they
+    were collected on."""
+    if (args.batch_size, args.max_node_count, args.num_operations) != (512, 100, 1001):
+        return None
+    try:
+        with open(TRAFFIC_PROFILE) as f:
+            return float(json.load(f)['family_bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse_args():
@@ -191,7 +207,8 @@ def main():
             tf = g[1] / (g[2] * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel', 'achieved': tf,
                     'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': tf / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'frac': tf / F32_MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(args),
+                    'traffic_unit': 'bytes/launch (profiles/r01b_hbm_traffic.json)',
                     'launches': g[0], 'avg_ms': g[2] / max(g[0], 1),
                     'share_of_step': g[2] * 1e-3 / elapsed}
         others = {}
