@@ -2,15 +2,23 @@
 //
 //   C[M,N] = row_scale[m] * (op(A)[M,K] . op(B)[K,N]) + bias[n]      (fp32 in, fp32 accumulate)
 //
-// v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32 fma chain, which is what the 1e-4
-// parity bound on losses / scores needs (no reduced-precision path is used).
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain, which is what the 1e-4 parity bound on
+// losses / scores needs (no reduced-precision path is used).
 //
 // Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave owns a
-// 64x64 block = 2x2 MFMA tiles of 32x32 -> 64 accumulator registers), BK = 32.
-// Both operands are staged through LDS in [k][m] order (row stride 132 floats), so the MFMA
-// operand read is one conflict-free ds_read_b32 per lane (lanes 0-31 read 32 consecutive
-// floats of row k, lanes 32-63 of row k+1).  Global -> register -> LDS with two LDS buffers:
-// the loads of tile t+1 are in flight while tile t is multiplied, one barrier per tile.
+// 64x64 block = 2x2 MFMA tiles of 32x32 -> 64 accumulator registers), BK = 32, two workgroups
+// per CU.  An operand tile is staged in LDS in the orientation it has in memory, so staging is
+// a 16-byte load and a 16-byte LDS store with no transposition:
+//   row-major ([x][k] storage): LDS [x][k], row stride 36 floats; a lane's MFMA operands for one
+//     8-deep k-block are ONE ds_read_b128 (4 consecutive k of its row, conflict-free at stride 36)
+//   k-major ([k][x] storage):   LDS [k][x], row stride 132 floats; one ds_read_b32 per k-step
+// In both, lanes 0-31 hold k = 8*kb + s and lanes 32-63 hold k = 8*kb + 4 + s for step s of
+// k-block kb: an MFMA step multiplies that k pair (a fixed summation order, the same for A and B).
+// Pipeline (one barrier per tile): barrier; write the registers holding tile t+1 into the other
+// LDS buffer; issue the global loads of tile t+2; multiply tile t.  Loads therefore have a whole
+// tile of matrix work to land, and the LDS stores sit behind the first MFMAs of the tile.
+// Edges: out-of-range rows/columns read a clamped (valid) address and only ever reach
+// accumulators that are not stored; the one partial k-tile is loaded through a masked path.
 // Workgroup ids are remapped so that the workgroups sharing an XCD (ids equal mod 8) walk a
 // contiguous range of tiles, n fastest: an A panel is then fetched into one L2 only.
 // Bound: MFMA (157.3 TFLOP/s fp32 dense peak); algorithmic flops = 2*M*N*K.
@@ -22,8 +30,9 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDS_STRIDE = 132;              // floats; 528 B rows keep 16-B alignment
-constexpr int TILE_FLOATS = BK * LDS_STRIDE; // one operand, one buffer
+constexpr int SX = 36;                        // row stride of an [x][k] tile (floats)
+constexpr int SK = 132;                       // row stride of a [k][x] tile
+constexpr int TILE_FLOATS = (BM * SX > BK * SK) ? BM * SX : BK * SK;  // one operand, one buffer
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -39,92 +48,107 @@ struct GemmArgs {
   int a_vec, b_vec;          // 16-byte loads allowed for the operand (host-side dispatch)
 };
 
-// Tile staging.  One operand tile is 128 (x) by 32 (k) floats, 16 floats per thread.
-// Every load is unconditional from a clamped (always valid) address and zeroed by a
-// select afterwards, so the main loop has no divergent branches.
-//   VEC  (16-B loads; needs ld % 4 == 0, 16-B aligned base, contiguous extent % 4 == 0)
-//     [X][K] storage: float4 = 4 consecutive k of row x = (t>>3) + 32*it, k = (t&7)*4
-//     [K][X] storage: float4 = 4 consecutive x of row k = (t>>5) + 8*it,  x = (t&31)*4
-//   scalar (any ld / alignment): element e = t + 256*i
-//     [X][K] storage: k = e & 31,  x = e >> 5     (32 consecutive floats of a row)
-//     [K][X] storage: x = e & 127, k = e >> 7     (128 consecutive floats of a k-row)
-template <bool KMAJOR, bool VEC>
-struct Stager {
+// Staging of one operand tile: 128 (x) by 32 (k) floats, 16 floats per thread.
+//   KX  = the operand is stored [k][x] (x contiguous), else [x][k] (k contiguous)
+//   VEC = 16-B loads (needs ld % 4 == 0, 16-B aligned base, contiguous extent % 4 == 0),
+//         else 4-B loads (any ld / alignment)
+// thread -> element maps (x, k local to the tile):
+//   [x][k] VEC:    float4 it: x = (t>>3) + 32*it, k = (t&7)*4 ..+3
+//   [k][x] VEC:    float4 it: k = (t>>5) + 8*it,  x = (t&31)*4 ..+3
+//   [x][k] scalar: element i: x = (t>>5) + 8*i,   k = t&31
+//   [k][x] scalar: element i: k = (t>>7) + 2*i,   x = t&127
+template <bool KX, bool VEC>
+struct Stage {
+  static constexpr int NL = VEC ? 4 : 16;
   float r[16];
-  unsigned okmask;   // validity of the staged loads; applied when the tile is written to LDS,
-                     // so that nothing consumes a load result before the MFMA phase
-  const float *base;
-  int64_t ld, x0, xlim;
+  unsigned off[NL];   // element offset of each load from the tile origin, x clamped into range
+  const float *tile;  // origin of the current tile (wave-uniform)
+  int64_t ld;
   int t;
 
-  __device__ __forceinline__ void init(const float *b, int64_t ld_, int64_t x0_, int64_t xlim_,
-                                       int t_) {
-    base = b; ld = ld_; x0 = x0_; xlim = xlim_; t = t_;
+  __device__ __forceinline__ int klocal(int i) const {
+    if (VEC) return KX ? (t >> 5) + 8 * i : (t & 7) * 4;
+    return KX ? (t >> 7) + 2 * i : (t & 31);
+  }
+  __device__ __forceinline__ int xlocal(int i) const {
+    if (VEC) return KX ? (t & 31) * 4 : (t >> 3) + 32 * i;
+    return KX ? (t & 127) : (t >> 5) + 8 * i;
   }
 
-  __device__ __forceinline__ void load(int64_t k0, int64_t klim) {
-    okmask = 0;
-    if (VEC) {
+  __device__ __forceinline__ void init(const float *base, int64_t ld_, int64_t x0, int64_t xlim,
+                                       int64_t k0, int t_) {
+    ld = ld_; t = t_;
+    tile = KX ? base + k0 * ld + x0 : base + x0 * ld + k0;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        int64_t x, k;
-        if (!KMAJOR) { x = x0 + (t >> 3) + 32 * it; k = k0 + (t & 7) * 4; }
-        else         { x = x0 + (t & 31) * 4;       k = k0 + (t >> 5) + 8 * it; }
-        const bool ok = (x < xlim) && (k < klim);
-        const int64_t xc = ok ? x : 0, kc = ok ? k : 0;
-        const float *p = KMAJOR ? (base + kc * ld + xc) : (base + xc * ld + kc);
-        const float4 v = *reinterpret_cast<const float4 *>(p);
-        r[4 * it + 0] = v.x; r[4 * it + 1] = v.y; r[4 * it + 2] = v.z; r[4 * it + 3] = v.w;
-        okmask |= ok ? (1u << it) : 0u;
+    for (int i = 0; i < NL; ++i) {
+      int x = xlocal(i);
+      // an out-of-range x only feeds accumulators that are never stored: read a valid element
+      if (x0 + x + (VEC && KX ? 3 : 0) >= xlim) x = (VEC && KX) ? 0 : (int)(xlim - 1 - x0);
+      off[i] = KX ? (unsigned)(klocal(i) * ld + x) : (unsigned)(x * ld + klocal(i));
+    }
+  }
+
+  __device__ __forceinline__ void advance() { tile += KX ? BK * ld : BK; }
+
+  // a full k-tile: unconditional loads
+  __device__ __forceinline__ void load() {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if (VEC) {
+        const float4 v = *reinterpret_cast<const float4 *>(tile + off[i]);
+        r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+      } else {
+        r[i] = tile[off[i]];
       }
-    } else {
+    }
+  }
+
+  // the partial last k-tile: k >= rem reads the tile's first k instead and is zeroed
+  __device__ __forceinline__ void load_tail(int rem) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        int64_t x, k;
-        if (!KMAJOR) { k = k0 + (t & 31);  x = x0 + (t >> 5) + 8 * i; }
-        else         { x = x0 + (t & 127); k = k0 + (t >> 7) + 2 * i; }
-        const bool ok = (x < xlim) && (k < klim);
-        const int64_t xc = ok ? x : 0, kc = ok ? k : 0;
-        r[i] = KMAJOR ? base[kc * ld + xc] : base[xc * ld + kc];
-        okmask |= ok ? (1u << i) : 0u;
+    for (int i = 0; i < NL; ++i) {
+      const int kl = klocal(i);
+      const bool ok = kl < rem;
+      const unsigned o = ok ? off[i] : off[i] - (KX ? (unsigned)(kl * ld) : (unsigned)kl);
+      if (VEC) {
+        const float4 v = *reinterpret_cast<const float4 *>(tile + o);
+        r[4 * i] = ok ? v.x : 0.f; r[4 * i + 1] = ok ? v.y : 0.f;
+        r[4 * i + 2] = ok ? v.z : 0.f; r[4 * i + 3] = ok ? v.w : 0.f;
+      } else {
+        const float v = tile[o];
+        r[i] = ok ? v : 0.f;
       }
     }
   }
 
   __device__ __forceinline__ void store(float *s) const {
-    if (VEC) {
-      if (!KMAJOR) {
-        const int k = (t & 7) * 4;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int x = (t >> 3) + 32 * it;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            s[(k + j) * LDS_STRIDE + x] = ((okmask >> it) & 1u) ? r[4 * it + j] : 0.f;
-        }
-      } else {
-        const int x = (t & 31) * 4;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int k = (t >> 5) + 8 * it;
-          const bool ok = (okmask >> it) & 1u;
-          *reinterpret_cast<float4 *>(&s[k * LDS_STRIDE + x]) =
-              make_float4(ok ? r[4 * it] : 0.f, ok ? r[4 * it + 1] : 0.f,
-                          ok ? r[4 * it + 2] : 0.f, ok ? r[4 * it + 3] : 0.f);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = ((okmask >> i) & 1u) ? r[i] : 0.f;
-        if (!KMAJOR) s[(t & 31) * LDS_STRIDE + (t >> 5) + 8 * i] = v;
-        else         s[((t >> 7) + 2 * i) * LDS_STRIDE + (t & 127)] = v;
-      }
+    for (int i = 0; i < NL; ++i) {
+      const int pos = KX ? klocal(i) * SK + xlocal(i) : xlocal(i) * SX + klocal(i);
+      if (VEC) *reinterpret_cast<float4 *>(&s[pos]) = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+      else s[pos] = r[i];
     }
   }
 };
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool A_VEC, bool B_VEC>
+// MFMA operands of k-block kb for the two 32-wide sub-tiles of a wave: f[sub][step]
+template <bool KX>
+__device__ __forceinline__ void read_fragments(const float *s, int w64, int lane, int kb,
+                                               float (&f)[2][4]) {
+  const int xl = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    if (!KX) {
+      const float4 v = *reinterpret_cast<const float4 *>(&s[(w64 + sub * 32 + xl) * SX + 8 * kb + 4 * kh]);
+      f[sub][0] = v.x; f[sub][1] = v.y; f[sub][2] = v.z; f[sub][3] = v.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f[sub][q] = s[(8 * kb + 4 * kh + q) * SK + w64 + sub * 32 + xl];
+    }
+  }
+}
+
+template <bool A_KX, bool B_KX, bool A_VEC, bool B_VEC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __align__(16) float smem[4 * TILE_FLOATS];  // A0 A1 B0 B1
   const int t = threadIdx.x;
@@ -145,7 +169,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int64_t m0 = tm * BM, n0 = tn * BN;
   const int64_t kbeg = sp * g.k_chunk;
   const int64_t kend = (kbeg + g.k_chunk < g.K) ? (kbeg + g.k_chunk) : g.K;
-  const int64_t nt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  const int64_t klen = kend > kbeg ? kend - kbeg : 0;
+  const int ntf = (int)(klen / BK);          // full k-tiles
+  const int rem = (int)(klen - (int64_t)ntf * BK);
+  const int nt = ntf + (rem ? 1 : 0);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -155,61 +182,56 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Stager<A_KMAJOR, A_VEC> sa;
-  Stager<B_KMAJOR, B_VEC> sb;
-  sa.init(g.A, g.lda, m0, g.M, t);
-  sb.init(g.B, g.ldb, n0, g.N, t);
+  Stage<A_KX, A_VEC> sa;
+  Stage<B_KX, B_VEC> sb;
+  sa.init(g.A, g.lda, m0, g.M, kbeg, t);
+  sb.init(g.B, g.ldb, n0, g.N, kbeg, t);
   float *As = smem, *Bs = smem + 2 * TILE_FLOATS;
 
   if (nt > 0) {
-    sa.load(kbeg, kend);
-    sb.load(kbeg, kend);
+    if (ntf > 0) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
     sa.store(As);
     sb.store(Bs);
   }
-  __syncthreads();
+  if (nt > 1) {
+    sa.advance(); sb.advance();
+    if (ntf > 1) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
+  }
 
-  const int kh = lane >> 5;   // which of the two k of an MFMA step this lane feeds
-  const int xl = lane & 31;
-  for (int64_t it = 0; it < nt; ++it) {
-    const int cur = (int)(it & 1);
-    const bool more = (it + 1 < nt);
-    if (more) {
-      const int64_t k0 = kbeg + (it + 1) * BK;
-      sa.load(k0, kend);
-      sb.load(k0, kend);
-    }
-    const float *as = As + cur * TILE_FLOATS + wm * 64 + xl + kh * LDS_STRIDE;
-    const float *bs = Bs + cur * TILE_FLOATS + wn * 64 + xl + kh * LDS_STRIDE;
-    // operand fragments are read one k-step ahead of the MFMAs that use them
-    float fa[2][2], fb[2][2];
-    fa[0][0] = as[0]; fa[0][1] = as[32]; fb[0][0] = bs[0]; fb[0][1] = bs[32];
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int c = (kk >> 1) & 1, nx = c ^ 1;
-      if (kk + 2 < BK) {
-        fa[nx][0] = as[(kk + 2) * LDS_STRIDE];
-        fa[nx][1] = as[(kk + 2) * LDS_STRIDE + 32];
-        fb[nx][0] = bs[(kk + 2) * LDS_STRIDE];
-        fb[nx][1] = bs[(kk + 2) * LDS_STRIDE + 32];
-      }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0], fb[c][1], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][0], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1], fb[c][1], acc[1][1], 0, 0, 0);
-      // pin the emitted order: the LDS reads of the next k-step go out before this step's
-      // four MFMAs, so their latency hides under 256 cycles of matrix work
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    }
-    if (more) {
+  for (int it = 0; it < nt; ++it) {
+    const int cur = it & 1;
+    __syncthreads();
+    if (it + 1 < nt) {
       sa.store(As + (cur ^ 1) * TILE_FLOATS);
       sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
     }
-    __syncthreads();
+    if (it + 2 < nt) {
+      sa.advance(); sb.advance();
+      if (it + 2 < ntf) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
+    }
+    const float *as = As + cur * TILE_FLOATS, *bs = Bs + cur * TILE_FLOATS;
+    float fa[2][2][4], fb[2][2][4];
+    read_fragments<A_KX>(as, wm * 64, lane, 0, fa[0]);
+    read_fragments<B_KX>(bs, wn * 64, lane, 0, fb[0]);
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      const int c = kb & 1;
+      if (kb + 1 < BK / 8) {
+        read_fragments<A_KX>(as, wm * 64, lane, kb + 1, fa[c ^ 1]);
+        read_fragments<B_KX>(bs, wn * 64, lane, kb + 1, fb[c ^ 1]);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][s], fb[c][0][s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][s], fb[c][1][s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][0][s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][1][s], acc[1][1], 0, 0, 0);
+      }
+    }
   }
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int kh = lane >> 5, xl = lane & 31;
   const bool split = g.splits > 1;
   float *out = split ? (g.slabs + sp * g.M * g.N) : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
@@ -291,6 +313,7 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
   TV_REQUIRE(ldb >= (trans_b ? k : n), "tv_gemm_f32: ldb %lld too small", (long long)ldb);
   TV_REQUIRE(ldc >= n, "tv_gemm_f32: ldc %lld too small", (long long)ldc);
   TV_REQUIRE(k > 0, "tv_gemm_f32: k must be positive");
+  TV_REQUIRE(lda < (1ll << 24) && ldb < (1ll << 24), "tv_gemm_f32: leading dimension too large");
 
   GemmArgs g;
   g.A = a; g.B = b; g.C = c; g.bias = bias; g.row_scale = row_scale;
