@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument('--score-steps', type=int, default=3)
     ap.add_argument('--cpu-baseline-traces', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gemm-shapes', action='store_true', help='per-shape GEMM table on stderr')
     ap.add_argument('--seed', type=int, default=1234)
     return ap.parse_args()
 
@@ -169,6 +170,11 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.TIMER.enabled = False
     kernel_summary = ops.TIMER.summary()
+    if args.gemm_shapes and rank == 0:
+        rows = sorted(ops.TIMER.by_tag('gemm_f32').items(), key=lambda kv: -kv[1][2])
+        for (m, n, k, ta, tb), (cnt, work, ms) in rows:
+            print(f'gemm m={m:7d} n={n:5d} k={k:7d} ta={int(ta)} tb={int(tb)}  x{cnt / args.steps:5.1f}/step '
+                  f'{ms / args.steps:7.3f} ms/step  {work / ms / 1e9:6.1f} TF', file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -51,6 +51,8 @@ def bench_gemm():
         ('mlp 512x500x500', False, True, 512, 500, 500),
         ('node-emb 512x4000x500', False, True, 512, 4000, 500),
         ('square 4096', False, True, 4096, 4096, 4096),
+        ('fwd  x.W^T dec (again)', False, True, 51200, 1000, 1000),
+        ('fwd  1024-aligned', False, True, 51200, 1024, 1024),
     ]
     for name, ta, tb, m, n, k in shapes:
         a = torch.randn((k, m) if ta else (m, k), device=DEV)

@@ -26,6 +26,7 @@
 // A reduction over many rows into a small output (weight gradients: M,N ~ 1000, K = rows)
 // is split over K into slabs and summed by a second kernel in slab order (deterministic).
 #include "tv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -44,6 +45,11 @@ struct GemmArgs {
   int64_t tiles_m, tiles_n;
   int64_t splits, k_chunk;   // k_chunk is a multiple of BK
   float *slabs;              // [splits, M, N] when splits > 1
+  // tail split: output tiles >= tail_first (the last, partial round of workgroups over the
+  // chip) are each computed by tail_splits workgroups over K/tail_splits, into packed
+  // 128x128 slabs [tile - tail_first][split], summed by gemm_tail_reduce_kernel
+  int64_t tail_first, tail_splits, tail_kchunk;
+  float *tail_slabs;
   int accumulate;
   int a_vec, b_vec;          // 16-byte loads allowed for the operand (host-side dispatch)
 };
@@ -156,22 +162,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware, bijective remap of the workgroup id (ids equal mod 8 share an XCD)
-  const int64_t nwg = gridDim.x;
-  const int64_t bid = blockIdx.x;
-  const int64_t q = nwg >> 3, rr = nwg & 7;
-  const int64_t xcd = bid & 7, idx = bid >> 3;
-  const int64_t L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-  const int64_t tn = L % g.tiles_n;
-  const int64_t tm = (L / g.tiles_n) % g.tiles_m;
-  const int64_t sp = L / (g.tiles_n * g.tiles_m);
+  // Workgroup id -> (output tile, k-split).  Ids below `remapped` are permuted so that the
+  // workgroups sharing an XCD (ids equal mod 8) walk a contiguous range of tiles, n fastest
+  // (bijective for any count); the tail-split units keep dispatch order so that the last,
+  // small units spread over all XCDs.  Everything here is wave-uniform: keep it in SGPRs.
+  const int tail_units = g.tail_splits > 1;
+  const int nwg = tail_units ? (int)g.tail_first : (int)gridDim.x;
+  const int bid = blockIdx.x;
+  int tile, sp;
+  int64_t kchunk;
+  const bool tail = tail_units && bid >= nwg;
+  if (tail) {
+    const int u = bid - nwg;
+    tile = nwg + u / (int)g.tail_splits;
+    sp = u % (int)g.tail_splits;
+    kchunk = g.tail_kchunk;
+  } else {
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int tiles = (int)(g.tiles_n * g.tiles_m);
+    tile = L % tiles;
+    sp = L / tiles;
+    kchunk = g.k_chunk;
+  }
+  tile = __builtin_amdgcn_readfirstlane(tile);
+  sp = __builtin_amdgcn_readfirstlane(sp);
+  const int tn = __builtin_amdgcn_readfirstlane(tile % (int)g.tiles_n);
+  const int tm = __builtin_amdgcn_readfirstlane(tile / (int)g.tiles_n);
 
-  const int64_t m0 = tm * BM, n0 = tn * BN;
-  const int64_t kbeg = sp * g.k_chunk;
-  const int64_t kend = (kbeg + g.k_chunk < g.K) ? (kbeg + g.k_chunk) : g.K;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t kbeg = sp * kchunk;
+  const int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
   const int64_t klen = kend > kbeg ? kend - kbeg : 0;
-  const int ntf = (int)(klen / BK);          // full k-tiles
-  const int rem = (int)(klen - (int64_t)ntf * BK);
+  const int ntf = __builtin_amdgcn_readfirstlane((int)(klen / BK));          // full k-tiles
+  const int rem = __builtin_amdgcn_readfirstlane((int)(klen - (int64_t)ntf * BK));
   const int nt = ntf + (rem ? 1 : 0);
 
   f32x16 acc[2][2];
@@ -232,8 +257,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int kh = lane >> 5, xl = lane & 31;
+  if (tail) {
+    float *slab = g.tail_slabs + ((int64_t)(tile - nwg) * g.tail_splits + sp) * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[(wm * 64 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * BN + wn * 64 + j * 32 + xl] =
+              acc[i][j][r];
+    return;
+  }
   const bool split = g.splits > 1;
-  float *out = split ? (g.slabs + sp * g.M * g.N) : g.C;
+  float *out = split ? (g.slabs + (int64_t)sp * g.M * g.N) : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
   const bool plain = split || (!g.row_scale && !g.accumulate);
 #pragma unroll
@@ -282,6 +319,92 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
+// second stage of the tail split: C tile = epilogue(sum_s slab[tile][s]) in split order.
+// One workgroup per 32 rows of a tail tile; a thread owns 4 consecutive columns.
+__global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(GemmArgs g) {
+  const int64_t rel = blockIdx.x >> 2;
+  const int64_t tile = g.tail_first + rel;
+  const int64_t tn = tile % g.tiles_n, tm = tile / g.tiles_n;
+  const int t = threadIdx.x;
+  const int c4 = (t & 31) * 4;
+  const float *slab = g.tail_slabs + rel * g.tail_splits * (BM * BN);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = (blockIdx.x & 3) * 32 + (t >> 5) + 8 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t s = 0; s < g.tail_splits; ++s) {
+      const float4 p = *reinterpret_cast<const float4 *>(&slab[s * (BM * BN) + rl * BN + c4]);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const int64_t row = tm * BM + rl;
+    if (row >= g.M) continue;
+    const float rs = g.row_scale ? g.row_scale[row] : 1.0f;
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t col = tn * BN + c4 + j;
+      if (col < g.N) {
+        float w = e[j] * rs;
+        if (g.bias) w += g.bias[col];
+        float *o = g.C + row * g.ldc + col;
+        if (g.accumulate) w += *o;
+        *o = w;
+      }
+    }
+  }
+}
+
+// workgroups resident at once: two per CU (LDS-bound)
+int64_t resident_workgroups() {
+  static int64_t slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    slots = 2 * (int64_t)cus;
+  }
+  return slots;
+}
+
+struct Plan {
+  int64_t splits, k_chunk;                          // whole-problem split-K
+  int64_t tail_first, tail_splits, tail_kchunk;     // tail split (mutually exclusive with it)
+  int64_t workspace_bytes;
+};
+
+int64_t choose_splits(int64_t m, int64_t n, int64_t k);
+
+Plan make_plan(int64_t m, int64_t n, int64_t k) {
+  Plan p;
+  const int64_t tiles = tv_cdiv(m, BM) * tv_cdiv(n, BN);
+  p.splits = choose_splits(m, n, k);
+  p.k_chunk = tv_cdiv(tv_cdiv(k, p.splits), BK) * BK;
+  p.splits = tv_cdiv(k, p.k_chunk);
+  p.tail_first = tiles; p.tail_splits = 1; p.tail_kchunk = p.k_chunk;
+  p.workspace_bytes = p.splits > 1 ? p.splits * m * n * (int64_t)sizeof(float) : 0;
+  const int64_t slots = resident_workgroups();
+  static const bool tail_enabled = [] { const char *e = getenv("TV_GEMM_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
+  if (tail_enabled && p.splits == 1 && tiles > slots && tiles < (1ll << 30)) {
+    const int64_t tail = tiles % slots;
+    if (tail > 0) {
+      int64_t ts = slots / tail;
+      const int64_t kmax = k / (4 * BK);             // at least 4 k-tiles per unit
+      if (ts > kmax) ts = kmax;
+      if (ts > 8) ts = 8;
+      if (ts >= 2) {
+        const int64_t kc = tv_cdiv(tv_cdiv(k, ts), BK) * BK;
+        ts = tv_cdiv(k, kc);
+        if (ts >= 2) {
+          p.tail_first = tiles - tail; p.tail_splits = ts; p.tail_kchunk = kc;
+          p.workspace_bytes = tail * ts * (int64_t)(BM * BN * sizeof(float));
+        }
+      }
+    }
+  }
+  return p;
+}
+
 int64_t choose_splits(int64_t m, int64_t n, int64_t k) {
   const int64_t tiles = tv_cdiv(m, BM) * tv_cdiv(n, BN);
   if (tiles >= 256 || k < 8 * BK) return 1;
@@ -297,8 +420,7 @@ int64_t choose_splits(int64_t m, int64_t n, int64_t k) {
 
 extern "C" int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   if (m <= 0 || n <= 0 || k <= 0) return 0;
-  const int64_t s = choose_splits(m, n, k);
-  return s > 1 ? s * m * n * (int64_t)sizeof(float) : 0;
+  return make_plan(m, n, k).workspace_bytes;
 }
 
 extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k,
@@ -319,25 +441,27 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
   g.A = a; g.B = b; g.C = c; g.bias = bias; g.row_scale = row_scale;
   g.M = m; g.N = n; g.K = k; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.tiles_m = tv_cdiv(m, BM); g.tiles_n = tv_cdiv(n, BN);
-  g.splits = choose_splits(m, n, k);
-  g.k_chunk = tv_cdiv(tv_cdiv(k, g.splits), BK) * BK;
-  g.splits = tv_cdiv(k, g.k_chunk);
-  g.slabs = nullptr;
+  const Plan plan = make_plan(m, n, k);
+  g.splits = plan.splits; g.k_chunk = plan.k_chunk;
+  g.tail_first = plan.tail_first; g.tail_splits = plan.tail_splits; g.tail_kchunk = plan.tail_kchunk;
+  g.slabs = nullptr; g.tail_slabs = nullptr;
   g.accumulate = accumulate;
   // 16-B loads need aligned rows and a contiguous extent that is a multiple of 4
   g.a_vec = (lda % 4 == 0) && (((uintptr_t)a & 15) == 0) && ((trans_a ? m : k) % 4 == 0);
   g.b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0) && ((trans_b ? k : n) % 4 == 0);
-  if (g.splits > 1) {
-    const int64_t need = g.splits * m * n * (int64_t)sizeof(float);
+  if (plan.workspace_bytes > 0) {
+    const int64_t need = plan.workspace_bytes;
     if (!workspace || workspace_bytes < need) {
       tv_set_error("tv_gemm_f32: workspace of %lld bytes needed, %lld given", (long long)need,
                    (long long)workspace_bytes);
       return TV_ERR_WORKSPACE;
     }
-    g.slabs = (float *)workspace;
+    if (g.splits > 1) g.slabs = (float *)workspace; else g.tail_slabs = (float *)workspace;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int64_t nwg = g.tiles_m * g.tiles_n * g.splits;
+  const int64_t tiles = g.tiles_m * g.tiles_n;
+  const int64_t nwg = g.tail_splits > 1 ? g.tail_first + (tiles - g.tail_first) * g.tail_splits
+                                        : tiles * g.splits;
   TV_REQUIRE(nwg < (1ll << 31), "tv_gemm_f32: grid too large");
   const dim3 grid((unsigned)nwg), block(256);
   const int variant = (trans_a != 0 ? 8 : 0) | (trans_b == 0 ? 4 : 0) | (g.a_vec ? 2 : 0) |
@@ -361,6 +485,11 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g);
     TV_LAUNCH_CHECK("tv_gemm_f32(split-k reduce)");
+  }
+  if (g.tail_splits > 1) {
+    hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)((tiles - g.tail_first) * 4)), dim3(256),
+                       0, s, g);
+    TV_LAUNCH_CHECK("tv_gemm_f32(tail reduce)");
   }
   return TV_OK;
 }

@@ -119,26 +119,44 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(int64_t rows, int64_
   }
 }
 
-// one workgroup per operation id: dW[v,:] = sum over rows with ids[r] == v, in row order
-// within each of the 4 row groups, the groups combined in group order
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(int64_t rows, int64_t dim,
+// dW[v,:] = sum over rows with ids[r] == v.  One workgroup per EMB_VB consecutive operation
+// ids; its 4 waves scan the id list in 64-row chunks (chunk c belongs to wave c % 4), pick the
+// matching rows with a ballot and add them, in row order, into the wave's LDS partial; the four
+// partials are combined in wave order.  Fixed summation order, no atomics; every dout row is
+// read by exactly one workgroup.
+constexpr int EMB_VB = 4;
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(int64_t rows, int64_t dim, int64_t V,
                                                             const int64_t *__restrict__ ids,
                                                             const float *__restrict__ dout,
                                                             int64_t ld, int64_t col0,
                                                             float *__restrict__ dw) {
-  __shared__ float part[4][64];
-  const int64_t v = blockIdx.x;
+  __shared__ float part[4][EMB_VB][64];
+  const int64_t v0 = (int64_t)blockIdx.x * EMB_VB;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   for (int64_t d0 = 0; d0 < dim; d0 += 64) {
     const int64_t d = d0 + lane;
-    float acc = 0.f;
-    for (int64_t r = grp; r < rows; r += 4) {
-      if (ids[r] == v && d < dim) acc += dout[r * ld + col0 + d];
+#pragma unroll
+    for (int j = 0; j < EMB_VB; ++j) part[grp][j][lane] = 0.f;
+    for (int64_t r0 = (int64_t)grp * 64; r0 < rows; r0 += 256) {
+      const int64_t r = r0 + lane;
+      int64_t id = r < rows ? ids[r] : -1;
+      id = (r < rows) ? (id < 0 ? 0 : (id >= V ? V - 1 : id)) : -1;   // clamp like the forward
+      const int rel = (int)(id - v0);
+      unsigned long long hits = __ballot(rel >= 0 && rel < EMB_VB);
+      while (hits) {
+        const int bit = __builtin_ctzll(hits);
+        hits &= hits - 1;
+        const int j = __shfl(rel, bit);
+        if (d < dim) part[grp][j][lane] += dout[(r0 + bit) * ld + col0 + d];
+      }
     }
-    part[grp][lane] = acc;
     __syncthreads();
-    if (grp == 0 && d < dim)
-      dw[v * dim + d] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (grp == 0 && d < dim) {
+#pragma unroll
+      for (int j = 0; j < EMB_VB; ++j)
+        if (v0 + j < V)
+          dw[(v0 + j) * dim + d] = ((part[0][j][lane] + part[1][j][lane]) + part[2][j][lane]) + part[3][j][lane];
+    }
     __syncthreads();
   }
 }
@@ -259,8 +277,8 @@ extern "C" int tv_embedding_bwd(int64_t rows, int64_t dim, int64_t num_operation
   TV_REQUIRE(rows >= 0 && dim >= 1 && num_operations >= 1, "tv_embedding_bwd: bad sizes");
   TV_REQUIRE(col0 >= 0 && ld >= col0 + dim, "tv_embedding_bwd: columns do not fit ld");
   TV_REQUIRE(ids && dout && dweight, "tv_embedding_bwd: null pointer");
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)num_operations), dim3(256), 0,
-                     (hipStream_t)stream, rows, dim, ids, dout, ld, col0, dweight);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)tv_cdiv(num_operations, EMB_VB)), dim3(256),
+                     0, (hipStream_t)stream, rows, dim, num_operations, ids, dout, ld, col0, dweight);
   TV_LAUNCH_CHECK("tv_embedding_bwd");
   return TV_OK;
 }

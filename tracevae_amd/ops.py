@@ -34,8 +34,8 @@ class KernelTimer(object):
         self.records = {}
 
     class _Region(object):
-        def __init__(self, timer, name, work):
-            self.timer, self.name, self.work = timer, name, work
+        def __init__(self, timer, name, work, tag):
+            self.timer, self.name, self.work, self.tag = timer, name, work, tag
 
         def __enter__(self):
             self.start = torch.cuda.Event(enable_timing=True)
@@ -47,7 +47,7 @@ class KernelTimer(object):
             rec = self.timer.records.setdefault(self.name, [0, 0.0, []])
             rec[0] += 1
             rec[1] += self.work
-            rec[2].append((self.start, self.end))
+            rec[2].append((self.start, self.end, self.tag, self.work))
 
     class _Null(object):
         def __enter__(self):
@@ -58,17 +58,27 @@ class KernelTimer(object):
 
     _null = _Null()
 
-    def region(self, name, work):
+    def region(self, name, work, tag=None):
         if not self.enabled:
             return self._null
-        return self._Region(self, name, float(work))
+        return self._Region(self, name, float(work), tag)
 
     def summary(self):
         """{name: (launches, total work, total milliseconds)} - call after a device sync."""
         out = {}
         for name, (count, work, pairs) in self.records.items():
-            out[name] = (count, work, sum(a.elapsed_time(b) for a, b in pairs))
+            out[name] = (count, work, sum(p[0].elapsed_time(p[1]) for p in pairs))
         return out
+
+    def by_tag(self, name):
+        """{tag: (launches, total work, total milliseconds)} of one kernel family."""
+        out = {}
+        for start, end, tag, work in self.records.get(name, [0, 0.0, []])[2]:
+            rec = out.setdefault(tag, [0, 0.0, 0.0])
+            rec[0] += 1
+            rec[1] += work
+            rec[2] += start.elapsed_time(end)
+        return {k: tuple(v) for k, v in out.items()}
 
 
 TIMER = KernelTimer()
@@ -122,7 +132,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
         return c
     wsb = hip.query('tv_gemm_f32_workspace_bytes', m, n, k)
     ws = _workspace(wsb, a.device)
-    with TIMER.region('gemm_f32', 2.0 * m * n * k):
+    with TIMER.region('gemm_f32', 2.0 * m * n * k, (m, n, k, bool(trans_a), bool(trans_b))):
         hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr(a), a.stride(0),
                  hip.ptr(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
                  hip.ptr(row_scale), int(accumulate), hip.ptr(ws), wsb)
