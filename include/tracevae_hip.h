@@ -68,6 +68,14 @@ int64_t tv_stat_blocks(int64_t rows);
  *   adj [B, M(M-1)/2] f32, node_type_pad [B,M] i64, latency_pad [B,M] f32 (avg latency),
  *   node_count [B] i64, node_type [N] i64, latency [N,3] f32 (avg,min,max normalised as
  *   float32((double(x) - mean[op]) / (std[op] + 1e-5))), graph_id [N] i64.
+ *
+ * lat_row_weight != NULL additionally emits the COMPACT latency-decoder graph (the padded
+ * slots of one trace carry identical rows through model/latency_vae.py:320-343, so one
+ * representative per trace stands for its M - n_i slots): rows [real nodes (N) | one per
+ * trace (B)], i.e. the encoder graph plus B self-loop nodes.  The caller then sizes
+ * enc_src/enc_dst/enc_indices/enc_eids/enc_rev with E_enc + B entries, enc_indptr with
+ * N + B + 1, node_type and graph_id with N + B, and lat_row_weight [N + B] receives the
+ * BatchNorm weight of each row (1 for a node, M - n_i for a representative).
  * ---------------------------------------------------------------------------------- */
 int tv_batch_build(int64_t batch, int64_t max_node_count, int64_t total_nodes,
                    int64_t num_operations,
@@ -84,6 +92,7 @@ int tv_batch_build(int64_t batch, int64_t max_node_count, int64_t total_nodes,
                    int64_t *dec_indices, int64_t *dec_eids, int64_t *dec_rev, float *adj,
                    int64_t *node_type_pad, float *latency_pad, int64_t *node_count,
                    int64_t *node_type, float *latency, int64_t *graph_id,
+                   float *lat_row_weight, /* nullable, see above */
                    int32_t *status, /* device int32, OR-ed TV_BATCH_* bits; caller zeroes it */
                    void *stream);
 
@@ -134,7 +143,8 @@ int tv_colsum(int64_t rows, int64_t cols, const float *x, int64_t ldx, float *ou
  *   Optional fused epilogues:
  *     stats_partial != NULL : per-block column sum / sum of squares of `out`
  *                             [tv_stat_blocks(rows), 2, H*F] for the BatchNorm that follows
- *                             (gnn_layers.py:152-153, training mode);
+ *                             (gnn_layers.py:152-153, training mode); row v counts
+ *                             stats_row_weight[v] times when that is not NULL;
  *     ep_scale/ep_shift != NULL : y = LeakyReLU_slope(out*ep_scale + ep_shift) written to
  *                             `out` instead (eval-mode BatchNorm + activation, :152-155).
  * tv_gat_aggregate_bwd: gradients w.r.t. ft, attn_l, attn_r, bias given d(out).
@@ -144,8 +154,9 @@ int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const float *ft,
 int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
                          const int64_t *indptr, const int64_t *indices, const float *ft,
                          const float *el, const float *er, const float *bias, float *out,
-                         float *alpha, float *stats_partial, const float *ep_scale,
-                         const float *ep_shift, float ep_slope, void *stream);
+                         float *alpha, float *stats_partial, const float *stats_row_weight,
+                         const float *ep_scale, const float *ep_shift, float ep_slope,
+                         void *stream);
 int64_t tv_gat_aggregate_bwd_workspace_bytes(int64_t rows_per_rep, int64_t n_rep,
                                              int64_t heads, int64_t feats, int64_t num_edges);
 int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
@@ -160,16 +171,19 @@ int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
  * tk.layers.LeakyReLU; model/gnn_layers.py:152-155 and every `dense` of the MLPs,
  * model/struct_vae.py:117-120).
  *   tv_colstats        : partial[nblk,2,C] = per-block column sum / sum of squares
+ *                        (row r counts row_weight[r] times when row_weight != NULL)
  *   tv_bn_finalize     : mean, rstd (biased variance) from the partials, in float64;
  *                        running_mean/var updated with `momentum` (unbiased variance)
  *   tv_bn_apply_lrelu  : y = LeakyReLU_slope((x-mean)*rstd*gamma + beta)
  *   tv_affine_lrelu    : y = LeakyReLU_slope(x*scale + shift)   (eval mode, folded stats)
  *   tv_bn_eval_coeffs  : scale = gamma/sqrt(var+eps), shift = beta - mean*scale
- *   tv_bn_lrelu_bwd    : dx, dgamma, dbeta given dy (training mode: batch statistics)
+ *   tv_bn_lrelu_bwd    : dx, dgamma, dbeta given dy (training mode: batch statistics);
+ *                        count = rows, or the sum of row_weight when rows are weighted
  *   tv_affine_lrelu_bwd: dx = dy * lrelu'(x*scale+shift) * scale (eval mode inside a
  *                        training step: phase 2 of train.py:204-208)
  * ---------------------------------------------------------------------------------- */
-int tv_colstats(int64_t rows, int64_t cols, const float *x, float *partial, void *stream);
+int tv_colstats(int64_t rows, int64_t cols, const float *x, const float *row_weight,
+                float *partial, void *stream);
 int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, int64_t count, float eps,
                    float momentum, float *mean, float *rstd, float *running_mean,
                    float *running_var, void *stream);
@@ -184,8 +198,9 @@ int tv_affine_lrelu(int64_t rows, int64_t cols, const float *x, const float *sca
 int64_t tv_bn_lrelu_bwd_workspace_bytes(int64_t rows, int64_t cols);
 int tv_bn_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float *dy,
                     const float *mean, const float *rstd, const float *gamma, const float *beta,
-                    float slope, float *dx, float *dgamma, float *dbeta, void *workspace,
-                    int64_t workspace_bytes, void *stream);
+                    float slope, const float *row_weight, int64_t count, float *dx,
+                    float *dgamma, float *dbeta, void *workspace, int64_t workspace_bytes,
+                    void *stream);
 int tv_affine_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float *dy,
                         const float *scale, const float *shift, float slope, float *dx,
                         void *stream);
@@ -229,6 +244,17 @@ int tv_latdec_input_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count
                         void *stream);
 int tv_latdec_input_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count, int64_t z2_dim,
                         int64_t emb_dim, const float *dout, float *dz2, void *stream);
+/* the same on compact rows (see tv_batch_build): replica k holds rows_per_rep = N + B rows,
+ * row i belongs to trace row_graph[i] and has operation row_type[i];
+ * out[k*R + i] = [z2[k, row_graph[i]] || emb[row_type[i]]]; bwd sums a trace's node rows
+ * (node_offsets) and its representative row N + b. */
+int tv_latdec_rows_fwd(int64_t n_samples, int64_t rows_per_rep, int64_t batch, int64_t z2_dim,
+                       int64_t emb_dim, int64_t num_operations, const float *z2,
+                       const float *emb_weight, const int64_t *row_graph, const int64_t *row_type,
+                       float *out, void *stream);
+int tv_latdec_rows_bwd(int64_t n_samples, int64_t rows_per_rep, int64_t batch, int64_t z2_dim,
+                       int64_t emb_dim, const int64_t *node_offsets, const float *dout, float *dz2,
+                       void *stream);
 
 /* ------------------------------------------------------------------------------------
  * (c)/(d) likelihoods
@@ -282,18 +308,23 @@ int tv_normal_ll_bwd(int64_t rows, int64_t dim, const float *x, const float *mea
  * min(., log(max(std_limit[node_type_pad], 1e-7))) if std_limit != NULL;
  * mode 0 Normal, 1 SafeNormal(thr), 2 BiasedNormal(alpha, thr), 3 AnomalyDetectionNormal;
  * masked to m < node_count[b], weighted by M/node_count[b] when `weighted`.
- * ll [K,B]; optional std_out [K*B*M] (collect_latency_std, tensor_utils.py:155-169). */
+ * ll [K,B]; optional std_out [K*B*M] (collect_latency_std, tensor_utils.py:155-169).
+ * node_offsets != NULL: feats (and dfeats) are compact rows [K*(N+B), 2] (see tv_batch_build):
+ * slot m < n_b reads row node_offsets[b]+m, a padded slot the representative row N+b;
+ * needs use_mask. */
 int tv_latency_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                       const float *feats, const float *latency_pad, const int64_t *node_count,
-                      const int64_t *node_type_pad, const float *std_limit, int has_logstd_min,
-                      float logstd_min, int mode, float std_threshold, float alpha,
-                      float log_bias_threshold, int use_mask, int weighted, float *ll,
+                      const int64_t *node_type_pad, const int64_t *node_offsets,
+                      const float *std_limit, int has_logstd_min, float logstd_min, int mode,
+                      float std_threshold, float alpha, float log_bias_threshold, int use_mask,
+                      int weighted, float *ll,
                       float *std_out, void *stream);
 int tv_latency_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                       const float *feats, const float *latency_pad, const int64_t *node_count,
-                      const int64_t *node_type_pad, const float *std_limit, int has_logstd_min,
-                      float logstd_min, int mode, float std_threshold, float alpha,
-                      float log_bias_threshold, int use_mask, int weighted, const float *dll,
+                      const int64_t *node_type_pad, const int64_t *node_offsets,
+                      const float *std_limit, int has_logstd_min, float logstd_min, int mode,
+                      float std_threshold, float alpha, float log_bias_threshold, int use_mask,
+                      int weighted, const float *dll,
                       float *dfeats, void *stream);
 
 /* test-time scoring (evaluation.py:141-148): w = log_joint - latent_log_joint [K,B];

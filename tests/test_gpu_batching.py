@@ -107,3 +107,31 @@ def test_from_trace_graph_objects(device):
     for k in INT_KEYS:
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
     np.testing.assert_array_equal(got['adj'], want['adj'])
+
+
+def test_compact_latency_decoder_graph(device):
+    """tv_batch_build's compact latency-decoder graph: the encoder graph plus one self-loop
+    node per trace, with the BatchNorm weight of every row."""
+    from tracevae_amd.batch import DeviceTraceStore, build_device_batch
+    V, M = 30, 12
+    flat, lr = make_flat(9, V, M, seed=21)
+    db = build_device_batch(DeviceTraceStore(flat, lr, V), np.arange(len(flat)), M)
+    B, N = db.batch_size, db.num_nodes
+    E = db.enc.num_edges
+    lat = db.lat
+    assert lat.num_rows == N + B and lat.num_edges == E + B
+    for name in ('indptr', 'indices', 'eids', 'rev', 'src', 'dst'):
+        full, enc = getattr(lat, name).cpu(), getattr(db.enc, name).cpu()
+        assert torch.equal(full[:enc.shape[0]], enc), name
+    tail = torch.arange(B)
+    assert torch.equal(lat.indptr.cpu()[N:], E + torch.arange(B + 1))
+    for name in ('indices', 'src', 'dst'):
+        assert torch.equal(getattr(lat, name).cpu()[E:], N + tail), name
+    for name in ('eids', 'rev'):
+        assert torch.equal(getattr(lat, name).cpu()[E:], E + tail), name
+    w = db.lat_row_weight.cpu()
+    assert torch.equal(w[:N], torch.ones(N))
+    assert torch.equal(w[N:], (M - db.node_count.cpu()).float())
+    assert float(w.sum()) == B * M
+    assert torch.equal(db.lat_row_graph.cpu(), torch.cat([db.graph_id.cpu(), tail]))
+    assert torch.equal(db.lat_row_type.cpu(), torch.cat([db.node_type.cpu(), torch.zeros(B, dtype=torch.long)]))

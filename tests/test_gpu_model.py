@@ -64,6 +64,7 @@ def test_train_step_loss_and_gradients(device, V, M, width, layers, batch):
     trainer.flat.zero_grad()
     out = trainer.forward_loss(G, eps={'z': eps_z, 'z2': eps_z2})
     out['loss'].backward()
+    assert vae.latency_vae.last_compact    # the latency decoder ran on compact rows
     for k in ('loss', 'recons', 'kl'):
         assert rel_err(out[k], ref[k]) < PATH_TOL, k
     chain = out['chain']
@@ -124,8 +125,11 @@ def test_eval_step_scores(device, use_flow):
                                  latency_log_prob_weight=True, std_limit=std_limit.to(device),
                                  clip_nll=100_000.0, eps={'z': eps_z, 'z2': eps_z2},
                                  return_chain=True)
+    assert vae.latency_vae.last_compact
     assert rel_err(nll, ref['nll']) < PATH_TOL
     assert rel_err(loss, ref['loss']) < PATH_TOL
+    assert rel_err(chain.p['latency'].distribution.base_distribution.mean,
+                   ref['p']['latency_mean']) < PATH_TOL
     # the reference-style accessors give the same numbers
     assert rel_err(-chain.vi.evaluation.is_loglikelihood(), ref['nll'].clamp(max=1e30)) < PATH_TOL
     assert rel_err(chain.p['latency'].distribution.base_distribution.std,
@@ -201,3 +205,52 @@ def test_phase2_latency_only(device):
     for k, v in rm_before.items():
         changed = not torch.equal(sd[k], v)
         assert changed == k.startswith('latency_vae.'), k
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_compact_latency_decoder_equals_padded(device, monkeypatch, training):
+    """The compact latency decoder (one representative row per trace for its padded slots,
+    weighted in the BatchNorm statistics) is the same function as the reference's padded
+    [B*M]-row decoder: losses, gradients, running statistics and the mean/std accessors."""
+    import tracevae_amd.model as model
+    from tracevae_amd.batch import TraceGraphBatch
+    V, M, K = 60, 16, 3
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 2, 9, seed=11)
+    vae.train(training)
+    B = len(flat)
+    g = torch.Generator().manual_seed(5)
+    shape = (B, 10) if training else (K, B, 10)
+    eps = {'z': torch.randn(*shape, generator=g), 'z2': torch.randn(*shape, generator=g)}
+    state = {k: v.clone() for k, v in vae.state_dict().items()}
+    results = {}
+    for compact in (True, False):
+        monkeypatch.setattr(model, 'COMPACT_LATENCY_DECODER', compact)
+        vae.load_state_dict(state)
+        vae.zero_grad()
+        G = TraceGraphBatch.from_store(store, np.arange(B), M)
+        n_z = None if training else K
+        with torch.set_grad_enabled(training):
+            chain = vae.q(G, n_z=n_z, eps=eps).chain(
+                vae.p, G=G, latent_axis=None if training else 0,
+                **({} if training else dict(use_biased=True, latency_log_prob_weight=True)))
+            ll = chain.p['latency'].log_prob()
+            if training:
+                ll.sum().backward()
+        assert vae.latency_vae.last_compact == compact
+        base = chain.p['latency'].distribution.base_distribution
+        results[compact] = dict(
+            ll=ll.detach().clone(), mean=base.mean.detach().clone(), std=base.std.detach().clone(),
+            grads={n: p.grad.clone() for n, p in vae.named_parameters() if p.grad is not None},
+            stats={k: v.clone() for k, v in vae.state_dict().items() if 'running_' in k})
+    a, b = results[True], results[False]
+    assert rel_err(a['ll'], b['ll']) < 1e-5
+    assert rel_err(a['std'], b['std']) < 1e-5
+    assert rel_err(a['mean'], b['mean']) < 1e-5
+    for k in b['stats']:
+        assert rel_err(a['stats'][k], b['stats'][k]) < 1e-5, k
+    if training:
+        assert set(a['grads']) == set(b['grads'])
+        gmax = max(float(v.abs().max()) for v in b['grads'].values())
+        for n, want in b['grads'].items():
+            scale = max(float(want.abs().max()), 1e-4 * gmax)
+            assert float((a['grads'][n] - want).abs().max()) / scale < 1e-3, n

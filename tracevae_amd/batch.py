@@ -85,6 +85,8 @@ class DeviceBatch(object):
         'batch_size', 'num_nodes', 'max_node_count', 'node_offsets', 'node_offsets_host',
         'enc', 'dec', 'adj', 'node_type_pad', 'latency_pad', 'node_count', 'node_type',
         'latency', 'graph_id', 'status',
+        # compact latency-decoder graph: rows [real nodes | one per trace], see tv_batch_build
+        'lat', 'lat_row_weight', 'lat_row_graph', 'lat_row_type',
     ]
 
     def batch_num_nodes(self) -> torch.Tensor:
@@ -128,8 +130,13 @@ def build_device_batch(store: DeviceTraceStore, trace_ids: np.ndarray,
     i64 = lambda *shape: torch.empty(shape, dtype=torch.int64, device=dev)
     f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     # one allocation for all index outputs of each graph keeps the allocator quiet
-    enc_src, enc_dst, enc_indices, enc_eids, enc_rev = (i64(e_enc) for _ in range(5))
-    enc_indptr = i64(n + 1)
+    # the encoder arrays carry B more entries: with them they are the compact latency-decoder
+    # graph (encoder graph + one self-loop node per trace); the encoder graph is the prefix
+    lat_src, lat_dst, lat_indices, lat_eids, lat_rev = (i64(e_enc + b) for _ in range(5))
+    lat_indptr = i64(n + b + 1)
+    enc_src, enc_dst, enc_indices, enc_eids, enc_rev = (
+        t[:e_enc] for t in (lat_src, lat_dst, lat_indices, lat_eids, lat_rev))
+    enc_indptr = lat_indptr[:n + 1]
     dec_src, dec_dst, dec_indices, dec_eids, dec_rev = (i64(e_dec) for _ in range(5))
     dec_indptr = i64(b * m + 1)
     out = DeviceBatch()
@@ -139,9 +146,12 @@ def build_device_batch(store: DeviceTraceStore, trace_ids: np.ndarray,
     out.node_type_pad = i64(b, m)
     out.latency_pad = f32(b, m, 1)
     out.node_count = i64(b)
-    out.node_type = i64(n)
+    out.lat_row_type = i64(n + b)
+    out.lat_row_graph = i64(n + b)
+    out.lat_row_weight = f32(n + b)
+    out.node_type = out.lat_row_type[:n]
     out.latency = f32(n, 3)
-    out.graph_id = i64(n)
+    out.graph_id = out.lat_row_graph[:n]
     out.status = torch.zeros([1], dtype=torch.int32, device=dev)
     p = hip.ptr
     if b == 0:
@@ -150,6 +160,7 @@ def build_device_batch(store: DeviceTraceStore, trace_ids: np.ndarray,
         dec_indptr.zero_()
         out.enc = DeviceGraph(enc_indptr, enc_indices, enc_eids, enc_rev, enc_src, enc_dst)
         out.dec = DeviceGraph(dec_indptr, dec_indices, dec_eids, dec_rev, dec_src, dec_dst)
+        out.lat = out.enc
         return out
     hip.call('tv_batch_build', b, m, n, store.num_operations, p(d_off), p(d_nstart), p(d_estart),
              p(store.u), p(store.v), p(store.node_type), p(store.avg_latency),
@@ -157,8 +168,10 @@ def build_device_batch(store: DeviceTraceStore, trace_ids: np.ndarray,
              p(enc_src), p(enc_dst), p(enc_indptr), p(enc_indices), p(enc_eids), p(enc_rev),
              p(dec_src), p(dec_dst), p(dec_indptr), p(dec_indices), p(dec_eids), p(dec_rev),
              p(out.adj), p(out.node_type_pad), p(out.latency_pad), p(out.node_count),
-             p(out.node_type), p(out.latency), p(out.graph_id), p(out.status))
+             p(out.node_type), p(out.latency), p(out.graph_id), p(out.lat_row_weight),
+             p(out.status))
     out.enc = DeviceGraph(enc_indptr, enc_indices, enc_eids, enc_rev, enc_src, enc_dst)
+    out.lat = DeviceGraph(lat_indptr, lat_indices, lat_eids, lat_rev, lat_src, lat_dst)
     out.dec = DeviceGraph(dec_indptr, dec_indices, dec_eids, dec_rev, dec_src, dec_dst)
     if check and store.needs_status_check:
         out.check_status()

@@ -25,6 +25,7 @@ struct BatchArgs {
   int64_t *node_count, *node_type;
   float *latency;
   int64_t *graph_id;
+  float *lat_row_weight;   // optional: also emit the compact latency-decoder graph tails
   int32_t *status;
 };
 
@@ -52,6 +53,18 @@ __global__ __launch_bounds__(64) void batch_build_kernel(BatchArgs a) {
   const int64_t dbase = i * M;                  // first decoder node of this trace
   const bool last = (i == a.B - 1);
 
+  // Compact latency-decoder graph = encoder graph + one self-loop node per trace (row N + i)
+  // standing for the trace's M - n padded slots: the caller sized the encoder arrays, node_type
+  // and graph_id with B more entries.
+  if (a.lat_row_weight && lane == 0) {
+    const int64_t Et = 3 * a.N - 2 * a.B, p = Et + i, row = a.N + i;
+    a.enc_src[p] = row; a.enc_dst[p] = row;
+    a.enc_indices[p] = row; a.enc_eids[p] = p; a.enc_rev[p] = p;
+    a.enc_indptr[row + 1] = p + 1;
+    a.node_type[row] = 0;
+    a.graph_id[row] = i;
+    a.lat_row_weight[row] = (n64 >= 1 && n64 <= M) ? (float)(M - n64) : 0.f;
+  }
   if (n64 < 1 || n64 > M) {
     if (lane == 0) atomicOr(a.status, TV_BATCH_TOO_MANY_NODES);
     // keep the decoder structure of this slot well-formed (self loops only)
@@ -83,6 +96,7 @@ __global__ __launch_bounds__(64) void batch_build_kernel(BatchArgs a) {
     const int64_t t = a.store_node_type[sn + x];
     a.node_type[n0 + x] = t;
     a.graph_id[n0 + x] = i;
+    if (a.lat_row_weight) a.lat_row_weight[n0 + x] = 1.0f;
     a.node_type_pad[dbase + x] = t;
     double mu = 0.0, sd = 1.0;
     if (t < 0 || t >= a.V) {
@@ -203,8 +217,8 @@ extern "C" int tv_batch_build(
     int64_t *enc_indptr, int64_t *enc_indices, int64_t *enc_eids, int64_t *enc_rev,
     int64_t *dec_src, int64_t *dec_dst, int64_t *dec_indptr, int64_t *dec_indices,
     int64_t *dec_eids, int64_t *dec_rev, float *adj, int64_t *node_type_pad, float *latency_pad,
-    int64_t *node_count, int64_t *node_type, float *latency, int64_t *graph_id, int32_t *status,
-    void *stream) {
+    int64_t *node_count, int64_t *node_type, float *latency, int64_t *graph_id,
+    float *lat_row_weight, int32_t *status, void *stream) {
   TV_REQUIRE(batch >= 0 && total_nodes >= batch, "tv_batch_build: bad batch/total_nodes");
   TV_REQUIRE(max_node_count >= 2 && max_node_count <= 1536,
              "tv_batch_build: max_node_count must be in [2, 1536]: got %lld",
@@ -244,7 +258,7 @@ extern "C" int tv_batch_build(
   a.dec_indices = dec_indices; a.dec_eids = dec_eids; a.dec_rev = dec_rev;
   a.adj = adj; a.node_type_pad = node_type_pad; a.latency_pad = latency_pad;
   a.node_count = node_count; a.node_type = node_type; a.latency = latency;
-  a.graph_id = graph_id; a.status = status;
+  a.graph_id = graph_id; a.lat_row_weight = lat_row_weight; a.status = status;
   const size_t lds_bytes = sizeof(int32_t) * (size_t)(2 * M + (M + 1) + 6 * M);
   hipLaunchKernelGGL(batch_build_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, a);
   TV_LAUNCH_CHECK("tv_batch_build");

@@ -99,6 +99,7 @@ struct AggArgs {
   const int64_t *indptr, *indices, *rev;
   const float *ft, *el, *er, *bias, *attn_l, *attn_r, *alpha_in, *dout;
   float *out, *alpha, *stats_partial;
+  const float *row_weight;   // optional weights of the rows in the column statistics
   const float *ep_scale, *ep_shift;
   float ep_slope;
   // backward
@@ -202,15 +203,17 @@ __global__ __launch_bounds__(512) void gat_aggregate_fwd_kernel(AggArgs a) {
 
     // epilogue: + bias, optional fused BatchNorm(eval)+LeakyReLU or column statistics
     float4 *orow = reinterpret_cast<float4 *>(a.out + r * HF);
+    const float sw = (STATS && a.row_weight) ? a.row_weight[v] : 1.0f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int q = lane + 64 * c;
       if (q < c4) {
         float4 o = f4_add(acc[c], reinterpret_cast<const float4 *>(a.bias)[q]);
         if (STATS) {
-          ssum[c] = f4_add(ssum[c], o);
-          ssq[c] = make_float4(fmaf(o.x, o.x, ssq[c].x), fmaf(o.y, o.y, ssq[c].y),
-                               fmaf(o.z, o.z, ssq[c].z), fmaf(o.w, o.w, ssq[c].w));
+          const float4 wo = make_float4(sw * o.x, sw * o.y, sw * o.z, sw * o.w);
+          ssum[c] = f4_add(ssum[c], wo);
+          ssq[c] = make_float4(fmaf(wo.x, o.x, ssq[c].x), fmaf(wo.y, o.y, ssq[c].y),
+                               fmaf(wo.z, o.z, ssq[c].z), fmaf(wo.w, o.w, ssq[c].w));
         }
         if (EPILOGUE) {
           const float4 sc = reinterpret_cast<const float4 *>(a.ep_scale)[q];
@@ -499,8 +502,9 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
                                     int64_t feats, const int64_t *indptr, const int64_t *indices,
                                     const float *ft, const float *el, const float *er,
                                     const float *bias, float *out, float *alpha,
-                                    float *stats_partial, const float *ep_scale,
-                                    const float *ep_shift, float ep_slope, void *stream) {
+                                    float *stats_partial, const float *stats_row_weight,
+                                    const float *ep_scale, const float *ep_shift, float ep_slope,
+                                    void *stream) {
   if (int rc = check_shape("tv_gat_aggregate_fwd", rows_per_rep, n_rep, heads, feats)) return rc;
   const int64_t rows = rows_per_rep * n_rep;
   if (rows == 0) return TV_OK;
@@ -515,6 +519,7 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   a.H = (int)heads; a.F = (int)feats; a.c4 = (int)(heads * feats / 4);
   a.indptr = indptr; a.indices = indices; a.ft = ft; a.el = el; a.er = er; a.bias = bias;
   a.out = out; a.alpha = alpha; a.stats_partial = stats_partial;
+  a.row_weight = stats_row_weight;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_slope = ep_slope;
   // num_edges of one replica is only needed to index alpha; read back is avoided by
   // passing it through indptr on the host side of the caller: alpha is indexed with

@@ -191,6 +191,43 @@ __global__ __launch_bounds__(256) void latdec_input_bwd_kernel(int64_t KB, int64
   dz2[e] = acc;
 }
 
+// compact latency-decoder input: rows of one replica = [real nodes (N) | one representative
+// of the padded slots per trace (B)]; row i belongs to trace row_graph[i] and has operation
+// row_type[i]:  out[k*R + i] = [z2[k, row_graph[i]] || emb[row_type[i]]]
+__global__ __launch_bounds__(256) void latdec_rows_fwd_kernel(
+    int64_t K, int64_t R, int64_t B, int64_t Z, int64_t E, int64_t V,
+    const float *__restrict__ z2, const float *__restrict__ emb,
+    const int64_t *__restrict__ row_graph, const int64_t *__restrict__ row_type,
+    float *__restrict__ out) {
+  const int64_t W = Z + E, total = K * R * W, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t row = e / W, c = e - row * W;
+    const int64_t k = row / R, i = row - k * R;
+    if (c < Z) {
+      out[e] = z2[(k * B + row_graph[i]) * Z + c];
+    } else {
+      int64_t id = row_type[i];
+      id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+      out[e] = emb[id * E + (c - Z)];
+    }
+  }
+}
+
+// dz2[k,b,:] = sum of dout[:, :Z] over the rows of trace b, node order, representative last
+__global__ __launch_bounds__(256) void latdec_rows_bwd_kernel(
+    int64_t K, int64_t R, int64_t B, int64_t Z, int64_t W,
+    const int64_t *__restrict__ off, const float *__restrict__ dout, float *__restrict__ dz2) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= K * B * Z) return;
+  const int64_t kb = e / Z, d = e - kb * Z;
+  const int64_t k = kb / B, b = kb - k * B;
+  const int64_t N = off[B];
+  float acc = 0.f;
+  for (int64_t i = off[b]; i < off[b + 1]; ++i) acc += dout[(k * R + i) * W + d];
+  acc += dout[(k * R + N + b) * W + d];
+  dz2[e] = acc;
+}
+
 inline unsigned ew_blocks(int64_t work_items) {
   int64_t b = tv_cdiv(work_items, 256);
   if (b > 4096) b = 4096;
@@ -312,5 +349,38 @@ extern "C" int tv_latdec_input_bwd(int64_t n_samples, int64_t batch, int64_t max
                      0, (hipStream_t)stream, kb, max_node_count, z2_dim, z2_dim + emb_dim, dout,
                      dz2);
   TV_LAUNCH_CHECK("tv_latdec_input_bwd");
+  return TV_OK;
+}
+
+extern "C" int tv_latdec_rows_fwd(int64_t n_samples, int64_t rows_per_rep, int64_t batch,
+                                  int64_t z2_dim, int64_t emb_dim, int64_t num_operations,
+                                  const float *z2, const float *emb_weight,
+                                  const int64_t *row_graph, const int64_t *row_type, float *out,
+                                  void *stream) {
+  TV_REQUIRE(n_samples >= 1 && rows_per_rep >= 0 && batch >= 0 && z2_dim >= 1 && emb_dim >= 1 &&
+                 num_operations >= 1,
+             "tv_latdec_rows_fwd: bad sizes");
+  if (rows_per_rep == 0) return TV_OK;
+  TV_REQUIRE(z2 && emb_weight && row_graph && row_type && out, "tv_latdec_rows_fwd: null pointer");
+  const int64_t total = n_samples * rows_per_rep * (z2_dim + emb_dim);
+  hipLaunchKernelGGL(latdec_rows_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0,
+                     (hipStream_t)stream, n_samples, rows_per_rep, batch, z2_dim, emb_dim,
+                     num_operations, z2, emb_weight, row_graph, row_type, out);
+  TV_LAUNCH_CHECK("tv_latdec_rows_fwd");
+  return TV_OK;
+}
+
+extern "C" int tv_latdec_rows_bwd(int64_t n_samples, int64_t rows_per_rep, int64_t batch,
+                                  int64_t z2_dim, int64_t emb_dim, const int64_t *node_offsets,
+                                  const float *dout, float *dz2, void *stream) {
+  TV_REQUIRE(n_samples >= 1 && rows_per_rep >= batch && batch >= 0 && z2_dim >= 1 && emb_dim >= 0,
+             "tv_latdec_rows_bwd: bad sizes");
+  if (batch == 0) return TV_OK;
+  TV_REQUIRE(node_offsets && dout && dz2, "tv_latdec_rows_bwd: null pointer");
+  hipLaunchKernelGGL(latdec_rows_bwd_kernel,
+                     dim3((unsigned)tv_cdiv(n_samples * batch * z2_dim, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n_samples, rows_per_rep, batch, z2_dim,
+                     z2_dim + emb_dim, node_offsets, dout, dz2);
+  TV_LAUNCH_CHECK("tv_latdec_rows_bwd");
   return TV_OK;
 }

@@ -303,6 +303,7 @@ struct LatArgs {
   int64_t K, B, M;
   const float *feats, *latency_pad;
   const int64_t *node_count, *node_type_pad;
+  const int64_t *node_offsets;   // non-null: feats rows are compact ([real nodes | one per trace])
   const float *std_limit;
   int has_min;
   float ls_min;
@@ -325,9 +326,19 @@ __global__ __launch_bounds__(256) void latency_ll_kernel(LatArgs a, float *__res
     const float w = (a.use_mask && a.weighted) ? (float)a.M / (float)n : 1.0f;
     const float g0 = BWD ? dll[kb] * w : 0.f;
     float acc = 0.f;
+    // compact rows: replica k holds R = N + B rows, the real nodes of trace b at
+    // node_offsets[b].. and the representative of its padded slots at N + b
+    int64_t cbase = 0, crep = 0;
+    if (a.node_offsets) {
+      const int64_t N = a.node_offsets[a.B], k = kb / a.B;
+      cbase = k * (N + a.B) + a.node_offsets[b];
+      crep = k * (N + a.B) + N + b;
+      if (BWD && lane == 0) { dfeats[2 * crep] = 0.f; dfeats[2 * crep + 1] = 0.f; }
+    }
     for (int64_t m = lane; m < a.M; m += 64) {
       const int64_t r = kb * a.M + m;
-      const float mu = a.feats[2 * r], raw = a.feats[2 * r + 1];
+      const int64_t fr = a.node_offsets ? (m < n ? cbase + m : crep) : r;
+      const float mu = a.feats[2 * fr], raw = a.feats[2 * fr + 1];
       float ls = raw;
       bool pass = true;  // does d(ls)/d(raw) = 1 ?
       if (a.has_min && ls < a.ls_min) { ls = a.ls_min; pass = false; }
@@ -358,8 +369,10 @@ __global__ __launch_bounds__(256) void latency_ll_kernel(LatArgs a, float *__res
         acc += lp * (live ? 1.0f : 0.0f) * w;
       } else {
         const float g = live ? g0 * scale : 0.f;
-        dfeats[2 * r] = g * diff * prec;
-        dfeats[2 * r + 1] = pass ? g * (-1.0f + diff * diff * prec) : 0.f;
+        if (!a.node_offsets || m < n) {
+          dfeats[2 * fr] = g * diff * prec;
+          dfeats[2 * fr + 1] = pass ? g * (-1.0f + diff * diff * prec) : 0.f;
+        }
       }
     }
     if (!BWD) {
@@ -530,13 +543,15 @@ extern "C" int tv_normal_ll_bwd(int64_t rows, int64_t dim, const float *x, const
 static int fill_lat_args(LatArgs &a, const char *name, int64_t n_samples, int64_t batch,
                          int64_t max_node_count, const float *feats, const float *latency_pad,
                          const int64_t *node_count, const int64_t *node_type_pad,
-                         const float *std_limit, int has_logstd_min, float logstd_min, int mode,
-                         float std_threshold, float alpha, float log_bias_threshold, int use_mask,
-                         int weighted) {
+                         const int64_t *node_offsets, const float *std_limit, int has_logstd_min,
+                         float logstd_min, int mode, float std_threshold, float alpha,
+                         float log_bias_threshold, int use_mask, int weighted) {
   TV_REQUIRE(n_samples >= 1 && batch >= 0 && max_node_count >= 1, "%s: bad sizes", name);
   TV_REQUIRE(mode >= 0 && mode <= 3, "%s: mode must be 0..3", name);
   TV_REQUIRE(feats && latency_pad && node_count, "%s: null pointer", name);
   TV_REQUIRE(!std_limit || node_type_pad, "%s: std_limit needs node_type_pad", name);
+  TV_REQUIRE(!node_offsets || use_mask, "%s: compact rows need the node-count mask", name);
+  a.node_offsets = node_offsets;
   a.K = n_samples; a.B = batch; a.M = max_node_count; a.feats = feats;
   a.latency_pad = latency_pad; a.node_count = node_count; a.node_type_pad = node_type_pad;
   a.std_limit = std_limit; a.has_min = has_logstd_min; a.ls_min = logstd_min; a.mode = mode;
@@ -548,13 +563,14 @@ static int fill_lat_args(LatArgs &a, const char *name, int64_t n_samples, int64_
 extern "C" int tv_latency_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                                  const float *feats, const float *latency_pad,
                                  const int64_t *node_count, const int64_t *node_type_pad,
-                                 const float *std_limit, int has_logstd_min, float logstd_min,
-                                 int mode, float std_threshold, float alpha,
-                                 float log_bias_threshold, int use_mask, int weighted, float *ll,
+                                 const int64_t *node_offsets, const float *std_limit,
+                                 int has_logstd_min, float logstd_min, int mode,
+                                 float std_threshold, float alpha, float log_bias_threshold,
+                                 int use_mask, int weighted, float *ll,
                                  float *std_out, void *stream) {
   LatArgs a;
   if (int rc = fill_lat_args(a, "tv_latency_ll_fwd", n_samples, batch, max_node_count, feats,
-                             latency_pad, node_count, node_type_pad, std_limit, has_logstd_min,
+                             latency_pad, node_count, node_type_pad, node_offsets, std_limit, has_logstd_min,
                              logstd_min, mode, std_threshold, alpha, log_bias_threshold, use_mask,
                              weighted))
     return rc;
@@ -569,13 +585,14 @@ extern "C" int tv_latency_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_n
 extern "C" int tv_latency_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                                  const float *feats, const float *latency_pad,
                                  const int64_t *node_count, const int64_t *node_type_pad,
-                                 const float *std_limit, int has_logstd_min, float logstd_min,
-                                 int mode, float std_threshold, float alpha,
-                                 float log_bias_threshold, int use_mask, int weighted,
-                                 const float *dll, float *dfeats, void *stream) {
+                                 const int64_t *node_offsets, const float *std_limit,
+                                 int has_logstd_min, float logstd_min, int mode,
+                                 float std_threshold, float alpha, float log_bias_threshold,
+                                 int use_mask, int weighted, const float *dll, float *dfeats,
+                                 void *stream) {
   LatArgs a;
   if (int rc = fill_lat_args(a, "tv_latency_ll_bwd", n_samples, batch, max_node_count, feats,
-                             latency_pad, node_count, node_type_pad, std_limit, has_logstd_min,
+                             latency_pad, node_count, node_type_pad, node_offsets, std_limit, has_logstd_min,
                              logstd_min, mode, std_threshold, alpha, log_bias_threshold, use_mask,
                              weighted))
     return rc;

@@ -12,6 +12,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void colstats_kernel(int64_t rows, int64_t C,
                                                        const float *__restrict__ x,
+                                                       const float *__restrict__ row_weight,
                                                        float *__restrict__ partial) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t nblk = gridDim.y, by = blockIdx.y;
@@ -19,8 +20,9 @@ __global__ __launch_bounds__(256) void colstats_kernel(int64_t rows, int64_t C,
   float s = 0.f, q = 0.f;
   for (int64_t r = by; r < rows; r += nblk) {
     const float v = x[r * C + col];
-    s += v;
-    q = fmaf(v, v, q);
+    const float wv = row_weight ? row_weight[r] * v : v;
+    s += wv;
+    q = fmaf(wv, v, q);
   }
   partial[(by * 2 + 0) * C + col] = s;
   partial[(by * 2 + 1) * C + col] = q;
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     int64_t rows, int64_t C, const float *__restrict__ x, const float *__restrict__ dy,
     const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
-    const float *__restrict__ sums, float inv_n, float *__restrict__ dx) {
+    const float *__restrict__ sums, const float *__restrict__ row_weight, float inv_n,
+    float *__restrict__ dx) {
   const int64_t total = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
     const int64_t c = e % C;
@@ -154,7 +157,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float xh = (x[e] - mean[c]) * rs;
     const float pre = fmaf(g, xh, beta[c]);
     const float dyl = dy[e] * (pre > 0.f ? 1.f : slope);
-    dx[e] = g * rs * (dyl - sums[c] * inv_n - xh * sums[C + c] * inv_n);
+    // a row of weight w stands for w identical rows: the statistics move w times as much
+    const float wn = row_weight ? row_weight[e / C] * inv_n : inv_n;
+    dx[e] = g * rs * (dyl - sums[c] * wn - xh * sums[C + c] * wn);
   }
 }
 
@@ -183,13 +188,13 @@ inline bool vec_ok(int64_t C, const void *a, const void *b) {
 
 }  // namespace
 
-extern "C" int tv_colstats(int64_t rows, int64_t cols, const float *x, float *partial,
-                           void *stream) {
+extern "C" int tv_colstats(int64_t rows, int64_t cols, const float *x, const float *row_weight,
+                           float *partial, void *stream) {
   TV_REQUIRE(rows >= 1 && cols >= 1, "tv_colstats: empty input");
   TV_REQUIRE(x && partial, "tv_colstats: null pointer");
   const dim3 grid((unsigned)tv_cdiv(cols, 256), (unsigned)tv_stat_blocks_host(rows));
   hipLaunchKernelGGL(colstats_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, cols, x,
-                     partial);
+                     row_weight, partial);
   TV_LAUNCH_CHECK("tv_colstats");
   return TV_OK;
 }
@@ -260,10 +265,11 @@ extern "C" int64_t tv_bn_lrelu_bwd_workspace_bytes(int64_t rows, int64_t cols) {
 
 extern "C" int tv_bn_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float *dy,
                                const float *mean, const float *rstd, const float *gamma,
-                               const float *beta, float slope, float *dx, float *dgamma,
-                               float *dbeta, void *workspace, int64_t workspace_bytes,
-                               void *stream) {
-  TV_REQUIRE(rows >= 1 && cols >= 1, "tv_bn_lrelu_bwd: bad sizes");
+                               const float *beta, float slope, const float *row_weight,
+                               int64_t count, float *dx, float *dgamma, float *dbeta,
+                               void *workspace, int64_t workspace_bytes, void *stream) {
+  TV_REQUIRE(rows >= 1 && cols >= 1 && count >= 1, "tv_bn_lrelu_bwd: bad sizes");
+  TV_REQUIRE(row_weight || count == rows, "tv_bn_lrelu_bwd: count must equal rows without weights");
   TV_REQUIRE(x && dy && mean && rstd && gamma && beta && dx && dgamma && dbeta,
              "tv_bn_lrelu_bwd: null pointer");
   const int64_t need = tv_bn_lrelu_bwd_workspace_bytes(rows, cols);
@@ -283,7 +289,8 @@ extern "C" int tv_bn_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const
                      cols, nblk, partial, sums, dgamma, dbeta);
   TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(finalize)");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, s, rows,
-                     cols, x, dy, mean, rstd, gamma, beta, slope, sums, 1.0f / (float)rows, dx);
+                     cols, x, dy, mean, rstd, gamma, beta, slope, sums, row_weight,
+                     (float)(1.0 / (double)count), dx);
   TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(apply)");
   return TV_OK;
 }

@@ -20,6 +20,7 @@ The 10-dimensional RealNVP prior and a handful of `[B]`-sized reductions stay in
 ("excluded from kernel scope").
 """
 import math
+import os
 from typing import Dict, List, Mapping, Optional
 
 import torch
@@ -36,6 +37,9 @@ __all__ = ['TraceVAE', 'TraceStructVAE', 'TraceLatencyVAE', 'OperationEmbedding'
 
 # tensorkit's BatchNorm epsilon (believed 1e-6, SURVEY.md appendix B3 - unverified)
 BN_EPSILON = 1e-6
+# latency decoder on compact rows (real nodes + one representative per trace); '0' keeps the
+# reference's padded [B*M] rows (A/B switch for tests and measurements)
+COMPACT_LATENCY_DECODER = os.environ.get('TRACEVAE_COMPACT_LATDEC', '1') != '0'
 LRELU_SLOPE = 0.01
 
 
@@ -83,11 +87,12 @@ class BatchNorm(nn.Module):
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
         self.momentum, self.eps = momentum, eps
 
-    def forward_lrelu(self, x, stats=None):
+    def forward_lrelu(self, x, stats=None, row_weight=None, count=None):
         if self.training:
             self.num_batches_tracked += 1
         return ops.bn_lrelu(x, self.weight, self.bias, self.running_mean, self.running_var,
-                            self.training, self.eps, self.momentum, LRELU_SLOPE, stats)
+                            self.training, self.eps, self.momentum, LRELU_SLOPE, stats,
+                            row_weight, count)
 
     def eval_coeffs(self):
         return ops.bn_eval_coeffs(self.running_mean, self.running_var, self.weight, self.bias,
@@ -190,7 +195,10 @@ class GATConvAgg(nn.Module):
         self.gnn = _GATParams(input_dim, output_dim, num_heads)
         self.normalization = BatchNorm(self.output_dim) if use_batch_norm else None
 
-    def forward(self, graph: ops.DeviceGraph, h: torch.Tensor, n_rep: int = 1) -> torch.Tensor:
+    def forward(self, graph: ops.DeviceGraph, h: torch.Tensor, n_rep: int = 1,
+                row_weight=None, count=None) -> torch.Tensor:
+        """`row_weight` / `count`: rows that stand for several identical rows of the batch
+        (compact latency decoder); only the BatchNorm statistics see the difference."""
         g = self.gnn
         ft = ops.linear(h, g.fc.weight)
         bn = self.normalization
@@ -198,8 +206,9 @@ class GATConvAgg(nn.Module):
             out, _ = ops.gat_conv(ft, g.attn_l, g.attn_r, g.bias, graph, n_rep)
             return _Identity.lrelu(out)
         if bn.training:
-            out, stats = ops.gat_conv(ft, g.attn_l, g.attn_r, g.bias, graph, n_rep, want_stats=True)
-            return bn.forward_lrelu(out, stats)
+            out, stats = ops.gat_conv(ft, g.attn_l, g.attn_r, g.bias, graph, n_rep, want_stats=True,
+                                      stats_row_weight=row_weight)
+            return bn.forward_lrelu(out, stats, row_weight, count)
         if not torch.is_grad_enabled():
             # eval + no_grad: BatchNorm(running stats) + LeakyReLU ride in the aggregate epilogue
             scale, shift = bn.eval_coeffs()
@@ -254,23 +263,24 @@ class GNNSequential(nn.Module):
         super().__init__()
         self.gnn = nn.ModuleList(list(layers) + [tail])
 
-    def _run(self, graph, h, n_rep, tail_arg):
+    def _run(self, graph, h, n_rep, tail_arg, row_weight, count):
         for layer in list(self.gnn)[:-1]:
-            h = layer(graph, h, n_rep)
+            h = layer(graph, h, n_rep, row_weight, count)
         tail = self.gnn[len(self.gnn) - 1]
         if isinstance(tail, _Pooling):
             return tail(tail_arg, h)
         return tail(graph, h, n_rep)
 
-    def forward(self, graph: ops.DeviceGraph, h: torch.Tensor, n_rep: int = 1, batch=None):
+    def forward(self, graph: ops.DeviceGraph, h: torch.Tensor, n_rep: int = 1, batch=None,
+                row_weight=None, count=None):
         bn_training = any(isinstance(m, BatchNorm) and m.training for m in self.modules())
         if n_rep > 1 and bn_training:
             # apply_gnn_layer (gnn_layers.py:90-97): one pass per sample, so that batch
             # statistics are per sample like in the reference
             rows = h.shape[0] // n_rep
-            return torch.cat([self._run(graph, h[i * rows:(i + 1) * rows], 1, batch)
+            return torch.cat([self._run(graph, h[i * rows:(i + 1) * rows], 1, batch, row_weight, count)
                               for i in range(n_rep)], dim=0)
-        return self._run(graph, h, n_rep, batch)
+        return self._run(graph, h, n_rep, batch, row_weight, count)
 
 
 def make_gnn_layers(gnn_cfg, input_dim: int, sizes: List[int]):
@@ -600,8 +610,23 @@ class TraceLatencyVAE(nn.Module):
         emb_w = self.operation_embedding.weight
         if not dec.operation_embedding_stop_grad:
             raise NotImplementedError('operation_embedding_stop_grad=False is non-default')
-        h = ops.latdec_input(z2.reshape(-1, z2.shape[-1]), emb_w.detach(), node_type, n_rep)
-        feats = self.pG_node_features(batch.dec, h, n_rep)
+        # The padded slots of a trace all carry the same row [z2 || emb[0]] and only a self
+        # loop, so they stay identical through every layer: when the observed node types are
+        # the batch's own (teacher forcing, the only case on this path) and padded slots are
+        # masked out of the likelihood, ONE representative row per trace stands for its
+        # M - n padded slots, weighted accordingly in the BatchNorm statistics.  Same function
+        # of the parameters, about half the rows.
+        compact = COMPACT_LATENCY_DECODER and dec.use_latency_mask and \
+            node_type is batch.node_type_pad and batch.batch_size > 0
+        self.last_compact = bool(compact)
+        if compact:
+            h = ops.latdec_rows(z2.reshape(-1, z2.shape[-1]), emb_w.detach(), batch.lat_row_graph,
+                                batch.lat_row_type, batch.node_offsets, n_rep)
+            feats = self.pG_node_features(batch.lat, h, n_rep, None, batch.lat_row_weight,
+                                          batch.batch_size * M)
+        else:
+            h = ops.latdec_input(z2.reshape(-1, z2.shape[-1]), emb_w.detach(), node_type, n_rep)
+            feats = self.pG_node_features(batch.dec, h, n_rep)
 
         if latency_logstd_min is not None:
             if dec.latency_logstd_min is not None:
@@ -622,12 +647,26 @@ class TraceLatencyVAE(nn.Module):
             feats.contiguous(), batch.latency_pad, net['node_count'].tensor, node_type, n_rep,
             mode=mode, std_threshold=thr, alpha=alpha, bias_threshold=0.5,
             logstd_min=latency_logstd_min, std_limit=std_limit,
-            use_mask=dec.use_latency_mask, weighted=latency_log_prob_weight)
+            use_mask=dec.use_latency_mask, weighted=latency_log_prob_weight,
+            node_offsets=batch.node_offsets if compact else None)
         shape4 = lead + (M, C.LATENCY_DIM)
+        if compact:
+            feats_c, nb = feats, batch
+
+            def padded_mean():
+                # scatter the compact rows back to [.., B, M, 1] (off the hot path)
+                n, b = nb.num_nodes, nb.batch_size
+                slot = torch.arange(M, device=feats_c.device)[None, :]
+                idx = torch.where(slot < nb.node_count[:, None], nb.node_offsets[:b, None] + slot,
+                                  n + torch.arange(b, device=feats_c.device)[:, None])
+                idx = idx[None] + (n + b) * torch.arange(n_rep, device=feats_c.device)[:, None, None]
+                return feats_c[:, 0][idx.reshape(-1)].reshape(shape4)
+        else:
+            padded_mean = lambda: feats[:, :1].reshape(shape4)
         base = Distribution(
             {'safe': 'SafeNormal', 'biased': 'BiasedNormal', 'anomaly': 'AnomalyDetectionNormal',
              'normal': 'Normal'}[mode],
-            mean=lambda: feats[:, :1].reshape(shape4), std=lambda: std.reshape(shape4),
+            mean=padded_mean, std=lambda: std.reshape(shape4),
             logstd=lambda: torch.log(std).reshape(shape4))
         dist = Distribution('MaskedDistribution', base_distribution=base) \
             if dec.use_latency_mask else base

@@ -14,7 +14,7 @@ from . import hip
 
 __all__ = [
     'DeviceGraph', 'TIMER', 'gemm', 'linear', 'matmul_nn', 'rowdot', 'colsum', 'gat_conv', 'bn_lrelu',
-    'graph_sum', 'segment_mean', 'embedding', 'latdec_input', 'adj_bernoulli_ll',
+    'graph_sum', 'segment_mean', 'embedding', 'latdec_input', 'latdec_rows', 'adj_bernoulli_ll',
     'categorical_ll', 'normal_reparam', 'normal_ll', 'latency_ll', 'score_reduce',
     'LATENCY_MODES',
 ]
@@ -251,7 +251,7 @@ def rowdot(x, w):
 class _GATConv(Function):
     @staticmethod
     def forward(ctx, ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int, want_stats: bool,
-                ep_scale, ep_shift, ep_slope: float, need_grad: bool):
+                ep_scale, ep_shift, ep_slope: float, need_grad: bool, stats_row_weight=None):
         ft = _check(ft, 'ft')
         heads, feats = int(attn_l.shape[-2]), int(attn_l.shape[-1])
         rows = ft.shape[0]
@@ -281,6 +281,7 @@ class _GATConv(Function):
             hip.call('tv_gat_aggregate_fwd', graph.num_rows, n_rep, heads, feats,
                      hip.ptr(graph.indptr), hip.ptr(graph.indices), hip.ptr(ft), hip.ptr(el),
                      hip.ptr(er), hip.ptr(bias), hip.ptr(out), hip.ptr(alpha), hip.ptr(stats),
+                     hip.ptr(stats_row_weight if want_stats else None),
                      hip.ptr(ep_scale), hip.ptr(ep_shift), float(ep_slope))
         if need_grad:
             ctx.save_for_backward(ft, el, er, alpha, al, ar)
@@ -318,19 +319,21 @@ class _GATConv(Function):
                      hip.ptr(dout), hip.ptr(dft), hip.ptr(dal), hip.ptr(dar), hip.ptr(dbias),
                      hip.ptr(ws), wsb)
         return (dft, dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape), dbias,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def gat_conv(ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int = 1,
-             want_stats: bool = False, ep_scale=None, ep_shift=None, ep_slope: float = 0.01):
+             want_stats: bool = False, ep_scale=None, ep_shift=None, ep_slope: float = 0.01,
+             stats_row_weight=None):
     """GATConv message passing after the fc projection.  Returns `(out, stats_partial)`;
-    `stats_partial` is an empty tensor unless `want_stats`."""
+    `stats_partial` is an empty tensor unless `want_stats` (rows counted `stats_row_weight`
+    times when given)."""
     # (grad mode is always off inside Function.forward, so decide here whether the
     # attention coefficients must be kept for a backward pass)
     need_grad = torch.is_grad_enabled() and any(
         t.requires_grad for t in (ft, attn_l, attn_r, bias))
     return _GATConv.apply(ft, attn_l, attn_r, bias, graph, n_rep, want_stats, ep_scale, ep_shift,
-                          ep_slope, need_grad)
+                          ep_slope, need_grad, stats_row_weight)
 
 
 # ---------------------------------------------------------------------------------------
@@ -338,19 +341,21 @@ def gat_conv(ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int = 1,
 # ---------------------------------------------------------------------------------------
 class _BNLReLUTrain(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope, stats):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope, stats,
+                row_weight=None, count=None):
         x = _check(x, 'x')
         rows, cols = x.shape
         dev = x.device
-        if rows < 2:
+        count = rows if row_weight is None else int(count)
+        if count < 2:
             raise ValueError('Expected more than 1 value per channel when training')
         if stats is None or stats.numel() == 0:
             stats = torch.empty([hip.query('tv_stat_blocks', rows), 2, cols], dtype=_f32, device=dev)
-            hip.call('tv_colstats', rows, cols, hip.ptr(x), hip.ptr(stats))
+            hip.call('tv_colstats', rows, cols, hip.ptr(x), hip.ptr(row_weight), hip.ptr(stats))
         nblk = stats.shape[0]
         mean = torch.empty([cols], dtype=_f32, device=dev)
         rstd = torch.empty([cols], dtype=_f32, device=dev)
-        hip.call('tv_bn_finalize', cols, nblk, hip.ptr(stats), rows, float(eps), float(momentum),
+        hip.call('tv_bn_finalize', cols, nblk, hip.ptr(stats), count, float(eps), float(momentum),
                  hip.ptr(mean), hip.ptr(rstd), hip.ptr(running_mean), hip.ptr(running_var))
         y = torch.empty_like(x)
         gamma, beta = _check(gamma, 'gamma'), _check(beta, 'beta')
@@ -358,6 +363,7 @@ class _BNLReLUTrain(Function):
                  hip.ptr(gamma), hip.ptr(beta), float(slope), hip.ptr(y))
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.slope = float(slope)
+        ctx.row_weight, ctx.count = row_weight, count
         return y
 
     @staticmethod
@@ -371,9 +377,9 @@ class _BNLReLUTrain(Function):
         wsb = hip.query('tv_bn_lrelu_bwd_workspace_bytes', rows, cols)
         ws = _workspace(wsb, x.device)
         hip.call('tv_bn_lrelu_bwd', rows, cols, hip.ptr(x), hip.ptr(dy), hip.ptr(mean),
-                 hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), ctx.slope, hip.ptr(dx),
-                 hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), wsb)
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+                 hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), ctx.slope, hip.ptr(ctx.row_weight),
+                 ctx.count, hip.ptr(dx), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), wsb)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class _AffineLReLU(Function):
@@ -410,12 +416,14 @@ def bn_eval_coeffs(running_mean, running_var, gamma, beta, eps: float):
 
 
 def bn_lrelu(x, gamma, beta, running_mean, running_var, training: bool, eps: float,
-             momentum: float = 0.1, slope: float = 0.01, stats=None):
+             momentum: float = 0.1, slope: float = 0.01, stats=None, row_weight=None, count=None):
     """BatchNorm over rows followed by LeakyReLU.  Training mode uses (and updates) batch
-    statistics; eval mode folds the running statistics into one affine pass."""
+    statistics; eval mode folds the running statistics into one affine pass.  With
+    `row_weight` [rows] a row stands for that many identical rows of the batch (`count` =
+    their total): statistics and the backward pass are those of the expanded batch."""
     if training:
         return _BNLReLUTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum,
-                                   slope, stats)
+                                   slope, stats, row_weight, count)
     with torch.no_grad():
         scale, shift = bn_eval_coeffs(running_mean, running_var, gamma, beta, eps)
     return _AffineLReLU.apply(x, scale, shift, slope)
@@ -536,6 +544,39 @@ class _LatDecInput(Function):
         dz2 = torch.empty(ctx.z2_shape, dtype=_f32, device=dout.device)
         hip.call('tv_latdec_input_bwd', k, b, m, zdim, edim, hip.ptr(dout), hip.ptr(dz2))
         return dz2, None, None, None
+
+
+class _LatDecRows(Function):
+    @staticmethod
+    def forward(ctx, z2, emb_weight, row_graph, row_type, node_offsets, n_samples: int):
+        z2 = _check(z2, 'z2')
+        emb_weight = _check(emb_weight, 'emb_weight')
+        rows, batch = row_graph.shape[0], node_offsets.shape[0] - 1
+        zdim, edim = z2.shape[-1], emb_weight.shape[1]
+        out = torch.empty([n_samples * rows, zdim + edim], dtype=_f32, device=z2.device)
+        hip.call('tv_latdec_rows_fwd', n_samples, rows, batch, zdim, edim, emb_weight.shape[0],
+                 hip.ptr(z2), hip.ptr(emb_weight), hip.ptr(row_graph), hip.ptr(row_type),
+                 hip.ptr(out))
+        ctx.dims = (n_samples, rows, batch, zdim, edim)
+        ctx.z2_shape = z2.shape
+        ctx.save_for_backward(node_offsets)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        k, rows, b, zdim, edim = ctx.dims
+        node_offsets, = ctx.saved_tensors
+        dout = _check(dout, 'dout')
+        dz2 = torch.empty(ctx.z2_shape, dtype=_f32, device=dout.device)
+        hip.call('tv_latdec_rows_bwd', k, rows, b, zdim, edim, hip.ptr(node_offsets),
+                 hip.ptr(dout), hip.ptr(dz2))
+        return dz2, None, None, None, None, None
+
+
+def latdec_rows(z2, emb_weight, row_graph, row_type, node_offsets, n_samples: int):
+    """Compact latency-decoder input: one row per real node plus one per trace."""
+    return _LatDecRows.apply(z2, emb_weight, row_graph, row_type, node_offsets, n_samples)
 
 
 def latdec_input(z2, emb_weight, node_type_pad, n_samples: int):
@@ -692,13 +733,15 @@ LATENCY_MODES = {'normal': 0, 'safe': 1, 'biased': 2, 'anomaly': 3}
 
 class _LatencyLL(Function):
     @staticmethod
-    def forward(ctx, feats, latency_pad, node_count, node_type_pad, std_limit, n_samples, cfg):
+    def forward(ctx, feats, latency_pad, node_count, node_type_pad, std_limit, n_samples, cfg,
+                node_offsets=None):
         feats = _check(feats, 'feats')
         batch, m = latency_pad.shape[0], latency_pad.shape[1]
         ll = torch.empty([n_samples * batch], dtype=_f32, device=feats.device)
         std_out = torch.empty([n_samples * batch * m], dtype=_f32, device=feats.device)
         args = (n_samples, batch, m, hip.ptr(feats), hip.ptr(latency_pad), hip.ptr(node_count),
-                hip.ptr(node_type_pad), hip.ptr(std_limit)) + cfg
+                hip.ptr(node_type_pad), hip.ptr(node_offsets), hip.ptr(std_limit)) + cfg
+        ctx.node_offsets = node_offsets
         hip.call('tv_latency_ll_fwd', *args, hip.ptr(ll), hip.ptr(std_out))
         ctx.save_for_backward(feats, latency_pad, node_count, node_type_pad,
                               std_limit if std_limit is not None else feats.new_empty(0))
@@ -717,20 +760,24 @@ class _LatencyLL(Function):
         batch, m = latency_pad.shape[0], latency_pad.shape[1]
         dfeats = torch.empty_like(feats)
         args = (ctx.n_samples, batch, m, hip.ptr(feats), hip.ptr(latency_pad), hip.ptr(node_count),
-                hip.ptr(node_type_pad), hip.ptr(std_limit)) + ctx.cfg
+                hip.ptr(node_type_pad), hip.ptr(ctx.node_offsets), hip.ptr(std_limit)) + ctx.cfg
         hip.call('tv_latency_ll_bwd', *args, hip.ptr(dll), hip.ptr(dfeats))
-        return dfeats, None, None, None, None, None, None
+        return dfeats, None, None, None, None, None, None, None
 
 
 def latency_ll(feats, latency_pad, node_count, node_type_pad, n_samples: int, *, mode: str,
                std_threshold: float = 0.0, alpha: float = 1.0, bias_threshold: float = 0.5,
-               logstd_min=None, std_limit=None, use_mask: bool = True, weighted: bool = False):
-    """feats [K*B*M, 2] -> (log p(latency) [K*B], std [K*B*M])."""
+               logstd_min=None, std_limit=None, use_mask: bool = True, weighted: bool = False,
+               node_offsets=None):
+    """feats [K*B*M, 2] -> (log p(latency) [K*B], std [K*B*M]).  With `node_offsets` [B+1]
+    feats are compact rows [K*(N+B), 2] (real nodes, then one row per trace for its padded
+    slots); std stays in the padded layout."""
     cfg = (int(logstd_min is not None), float(logstd_min if logstd_min is not None else 0.0),
            LATENCY_MODES[mode], float(std_threshold), float(alpha), math.log(bias_threshold),
            int(use_mask), int(weighted))
     lp = _check(latency_pad.reshape(latency_pad.shape[0], -1), 'latency_pad')
-    return _LatencyLL.apply(feats, lp, node_count, node_type_pad, std_limit, n_samples, cfg)
+    return _LatencyLL.apply(feats, lp, node_count, node_type_pad, std_limit, n_samples, cfg,
+                            node_offsets)
 
 
 def score_reduce(w: torch.Tensor, clip: Optional[float]):
