@@ -28,10 +28,16 @@ __device__ __forceinline__ float f4_dot(float4 a, float4 b) {
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
-__device__ __forceinline__ float sel_head(const float (&a)[MAXH], int h) {
+// value of head h out of HT per-head values.  The kernels are specialised on the head count
+// (1, 2, or up to MAXH) so that the common cases are a plain register select: a select chain
+// over a 4-entry array gets turned into an indexed scratch load by the compiler.
+template <int HT>
+__device__ __forceinline__ float sel_head(const float (&a)[HT], int h) {
+  if (HT == 1) return a[0];
+  if (HT == 2) return h ? a[1] : a[0];
   float r = a[0];
 #pragma unroll
-  for (int k = 1; k < MAXH; ++k) r = (h == k) ? a[k] : r;
+  for (int k = 1; k < HT; ++k) r = (h == k) ? a[k] : r;
   return r;
 }
 
@@ -106,7 +112,7 @@ struct AggArgs {
   float *dpre, *der, *dft, *partial;
 };
 
-template <int CH, bool STATS, bool EPILOGUE>
+template <int CH, int HT, bool STATS, bool EPILOGUE>
 __global__ __launch_bounds__(512) void gat_aggregate_fwd_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
@@ -132,40 +138,40 @@ __global__ __launch_bounds__(512) void gat_aggregate_fwd_kernel(AggArgs a) {
     const int64_t base = rep * a.rows_per_rep;
     const int64_t p0 = a.indptr[v];
     const int deg = (int)(a.indptr[v + 1] - p0);
-    float erv[MAXH];
+    float erv[HT];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) erv[h] = (h < H) ? a.er[r * H + h] : 0.f;
+    for (int h = 0; h < HT; ++h) erv[h] = (h < H) ? a.er[r * H + h] : 0.f;
 
     // pass 1: segment max of the edge scores
-    float mx[MAXH];
+    float mx[HT];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) mx[h] = -INFINITY;
+    for (int h = 0; h < HT; ++h) mx[h] = -INFINITY;
     for (int c0 = 0; c0 < deg; c0 += 64) {
       const int j = c0 + lane;
       if (j < deg) {
         const int64_t s = base + a.indices[p0 + j];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
+        for (int h = 0; h < HT; ++h)
           if (h < H) mx[h] = fmaxf(mx[h], tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE));
       }
     }
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) mx[h] = tv_wave_max(mx[h]);
+    for (int h = 0; h < HT; ++h) mx[h] = tv_wave_max(mx[h]);
     // pass 2: segment sum of exp
-    float den[MAXH];
+    float den[HT];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) den[h] = 0.f;
+    for (int h = 0; h < HT; ++h) den[h] = 0.f;
     for (int c0 = 0; c0 < deg; c0 += 64) {
       const int j = c0 + lane;
       if (j < deg) {
         const int64_t s = base + a.indices[p0 + j];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
+        for (int h = 0; h < HT; ++h)
           if (h < H) den[h] += expf(tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE) - mx[h]);
       }
     }
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) den[h] = tv_wave_sum(den[h]);
+    for (int h = 0; h < HT; ++h) den[h] = tv_wave_sum(den[h]);
 
     // pass 3: alpha per edge (one edge per lane), then the weighted neighbour sum
     float4 acc[CH];
@@ -174,13 +180,13 @@ __global__ __launch_bounds__(512) void gat_aggregate_fwd_kernel(AggArgs a) {
     for (int c0 = 0; c0 < deg; c0 += 64) {
       const int j = c0 + lane;
       int64_t s = 0;
-      float al[MAXH];
+      float al[HT];
 #pragma unroll
-      for (int h = 0; h < MAXH; ++h) al[h] = 0.f;
+      for (int h = 0; h < HT; ++h) al[h] = 0.f;
       if (j < deg) {
         s = base + a.indices[p0 + j];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
+        for (int h = 0; h < HT; ++h)
           if (h < H) {
             al[h] = expf(tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE) - mx[h]) / den[h];
             if (a.alpha) a.alpha[(rep * a.num_edges + p0 + j) * H + h] = al[h];
@@ -189,14 +195,14 @@ __global__ __launch_bounds__(512) void gat_aggregate_fwd_kernel(AggArgs a) {
       const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
       for (int jj = 0; jj < cnt; ++jj) {
         const int64_t sj = __shfl(s, jj, 64);
-        float aj[MAXH];
+        float aj[HT];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h) aj[h] = __shfl(al[h], jj, 64);
+        for (int h = 0; h < HT; ++h) aj[h] = __shfl(al[h], jj, 64);
         const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * HF);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int q = lane + 64 * c;
-          if (q < c4) acc[c] = f4_fma(sel_head(aj, hc[c]), srow[q], acc[c]);
+          if (q < c4) acc[c] = f4_fma(sel_head<HT>(aj, hc[c]), srow[q], acc[c]);
         }
       }
     }
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(512) void gat_aggregate_fwd_kernel(AggArgs a) {
 //   dpre_j= de_j * (pre_j > 0 ? 1 : 0.2)                    (LeakyReLU), pre_j = el[u_j]+er[v]
 //   der[v]= sum_j dpre_j ;  dpre kept per CSC position for step B
 // ------------------------------------------------------------------------------------
-template <int CH>
+template <int CH, int HT>
 __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
@@ -273,36 +279,36 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
 
     // pass 1: g_j for every in-edge (kept by lane j; spilled to dpre when deg > 64),
     // and s[h] = sum_j alpha_j g_j
-    float sacc[MAXH];
+    float sacc[HT];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) sacc[h] = 0.f;
-    float gkeep[MAXH];
+    for (int h = 0; h < HT; ++h) sacc[h] = 0.f;
+    float gkeep[HT];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) gkeep[h] = 0.f;
+    for (int h = 0; h < HT; ++h) gkeep[h] = 0.f;
     for (int c0 = 0; c0 < deg; c0 += 64) {
       const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
       const int j = c0 + lane;
       const int64_t s = (j < deg) ? (base + a.indices[p0 + j]) : 0;
-      float gj[MAXH];
+      float gj[HT];
 #pragma unroll
-      for (int h = 0; h < MAXH; ++h) gj[h] = 0.f;
+      for (int h = 0; h < HT; ++h) gj[h] = 0.f;
       for (int jj = 0; jj < cnt; ++jj) {
         const int64_t sj = __shfl(s, jj, 64);
         const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * HF);
-        float part[MAXH];
+        float part[HT];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h) part[h] = 0.f;
+        for (int h = 0; h < HT; ++h) part[h] = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int q = lane + 64 * c;
           if (q < c4) {
             const float dp = f4_dot(d[c], srow[q]);
 #pragma unroll
-            for (int h = 0; h < MAXH; ++h) part[h] += (hc[c] == h) ? dp : 0.f;
+            for (int h = 0; h < HT; ++h) part[h] += (hc[c] == h) ? dp : 0.f;
           }
         }
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h) {
+        for (int h = 0; h < HT; ++h) {
           if (h < H) {
             const float tot = tv_wave_sum(part[h]);
             if (lane == jj) gj[h] = tot;
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
       }
       if (j < deg) {
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
+        for (int h = 0; h < HT; ++h)
           if (h < H) {
             sacc[h] += a.alpha_in[(ebase + j) * H + h] * gj[h];
             if (deg > 64) a.dpre[(ebase + j) * H + h] = gj[h];
@@ -320,18 +326,18 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
       }
     }
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) sacc[h] = tv_wave_sum(sacc[h]);
+    for (int h = 0; h < HT; ++h) sacc[h] = tv_wave_sum(sacc[h]);
 
     // pass 2: softmax + LeakyReLU backward
-    float dsum[MAXH];
+    float dsum[HT];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) dsum[h] = 0.f;
+    for (int h = 0; h < HT; ++h) dsum[h] = 0.f;
     for (int c0 = 0; c0 < deg; c0 += 64) {
       const int j = c0 + lane;
       if (j < deg) {
         const int64_t s = base + a.indices[p0 + j];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
+        for (int h = 0; h < HT; ++h)
           if (h < H) {
             const float g = (deg > 64) ? a.dpre[(ebase + j) * H + h] : gkeep[h];
             const float al = a.alpha_in[(ebase + j) * H + h];
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
       }
     }
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) {
+    for (int h = 0; h < HT; ++h) {
       if (h < H) {
         const float tot = tv_wave_sum(dsum[h]);
         if (lane == 0) a.der[r * H + h] = tot;
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
 //   del[u]  = sum_p dpre[rev[p]]
 //   partial sums for dattn_l (del*ft), dattn_r (der*ft), dbias (dout)
 // ------------------------------------------------------------------------------------
-template <int CH>
+template <int CH, int HT>
 __global__ __launch_bounds__(512) void gat_bwd_node_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
@@ -388,45 +394,45 @@ __global__ __launch_bounds__(512) void gat_bwd_node_kernel(AggArgs a) {
     float4 acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float del[MAXH];
+    float del[HT];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) del[h] = 0.f;
+    for (int h = 0; h < HT; ++h) del[h] = 0.f;
 
     for (int c0 = 0; c0 < deg; c0 += 64) {
       const int j = c0 + lane;
       int64_t w = 0;
-      float al[MAXH], dp[MAXH];
+      float al[HT], dp[HT];
 #pragma unroll
-      for (int h = 0; h < MAXH; ++h) al[h] = dp[h] = 0.f;
+      for (int h = 0; h < HT; ++h) al[h] = dp[h] = 0.f;
       if (j < deg) {
         w = base + a.indices[p0 + j];
         const int64_t rp = eoff + a.rev[p0 + j];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
+        for (int h = 0; h < HT; ++h)
           if (h < H) {
             al[h] = a.alpha_in[rp * H + h];
             dp[h] = a.dpre[rp * H + h];
           }
       }
 #pragma unroll
-      for (int h = 0; h < MAXH; ++h) del[h] += dp[h];
+      for (int h = 0; h < HT; ++h) del[h] += dp[h];
       const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
       for (int jj = 0; jj < cnt; ++jj) {
         const int64_t wj = __shfl(w, jj, 64);
-        float aj[MAXH];
+        float aj[HT];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h) aj[h] = __shfl(al[h], jj, 64);
+        for (int h = 0; h < HT; ++h) aj[h] = __shfl(al[h], jj, 64);
         const float4 *wrow = reinterpret_cast<const float4 *>(a.dout + wj * HF);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int q = lane + 64 * c;
-          if (q < c4) acc[c] = f4_fma(sel_head(aj, hc[c]), wrow[q], acc[c]);
+          if (q < c4) acc[c] = f4_fma(sel_head<HT>(aj, hc[c]), wrow[q], acc[c]);
         }
       }
     }
-    float der[MAXH];
+    float der[HT];
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) {
+    for (int h = 0; h < HT; ++h) {
       del[h] = tv_wave_sum(del[h]);
       der[h] = (h < H) ? a.der[r * H + h] : 0.f;
     }
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(512) void gat_bwd_node_kernel(AggArgs a) {
     for (int c = 0; c < CH; ++c) {
       const int q = lane + 64 * c;
       if (q < c4) {
-        const float dl = sel_head(del, hc[c]), dr = sel_head(der, hc[c]);
+        const float dl = sel_head<HT>(del, hc[c]), dr = sel_head<HT>(der, hc[c]);
         const float4 wl = reinterpret_cast<const float4 *>(a.attn_l)[q];
         const float4 wr = reinterpret_cast<const float4 *>(a.attn_r)[q];
         orow[q] = f4_fma(dr, wr, f4_fma(dl, wl, acc[c]));
@@ -469,6 +475,21 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t nblk, int6
   float *o = (s == 0) ? o0 : (s == 1 ? o1 : o2);
   if (o) o[c] = (float)tot[0];
 }
+
+// launch KERNEL<CH, HT, ...> with CH = 4 or 8 float4 chunks per lane and HT = 1, 2 or MAXH heads
+#define TV_GAT_LAUNCH(KERNEL, GRID, BLOCK, LDSB, STREAM, ARGS, ...)                                \
+  do {                                                                                           \
+    const int ht_ = (ARGS).H == 1 ? 1 : ((ARGS).H == 2 ? 2 : MAXH);                              \
+    if ((ARGS).c4 > 256) {                                                                       \
+      if (ht_ == 1) hipLaunchKernelGGL((KERNEL<8, 1 __VA_ARGS__>), GRID, BLOCK, LDSB, STREAM, ARGS);      \
+      else if (ht_ == 2) hipLaunchKernelGGL((KERNEL<8, 2 __VA_ARGS__>), GRID, BLOCK, LDSB, STREAM, ARGS); \
+      else hipLaunchKernelGGL((KERNEL<8, MAXH __VA_ARGS__>), GRID, BLOCK, LDSB, STREAM, ARGS);            \
+    } else {                                                                                     \
+      if (ht_ == 1) hipLaunchKernelGGL((KERNEL<4, 1 __VA_ARGS__>), GRID, BLOCK, LDSB, STREAM, ARGS);      \
+      else if (ht_ == 2) hipLaunchKernelGGL((KERNEL<4, 2 __VA_ARGS__>), GRID, BLOCK, LDSB, STREAM, ARGS); \
+      else hipLaunchKernelGGL((KERNEL<4, MAXH __VA_ARGS__>), GRID, BLOCK, LDSB, STREAM, ARGS);            \
+    }                                                                                            \
+  } while (0)
 
 int check_shape(const char *name, int64_t rows_per_rep, int64_t n_rep, int64_t heads,
                 int64_t feats) {
@@ -533,18 +554,15 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   if (stats_partial) {
     const dim3 grid((unsigned)tv_stat_blocks_host(rows)), block(64 * TV_STAT_WAVES);
     const size_t ldsb = sizeof(float) * 2 * heads * feats;
-    if (big) hipLaunchKernelGGL((gat_aggregate_fwd_kernel<8, true, false>), grid, block, ldsb, s, a);
-    else hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, true, false>), grid, block, ldsb, s, a);
+    TV_GAT_LAUNCH(gat_aggregate_fwd_kernel, grid, block, ldsb, s, a, , true, false);
   } else {
     int64_t blocks = tv_cdiv(rows, TV_STAT_WAVES);
     if (blocks > 2048) blocks = 2048;
     const dim3 grid((unsigned)blocks), block(64 * TV_STAT_WAVES);
     if (ep_scale) {
-      if (big) hipLaunchKernelGGL((gat_aggregate_fwd_kernel<8, false, true>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, false, true>), grid, block, 0, s, a);
+      TV_GAT_LAUNCH(gat_aggregate_fwd_kernel, grid, block, 0, s, a, , false, true);
     } else {
-      if (big) hipLaunchKernelGGL((gat_aggregate_fwd_kernel<8, false, false>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((gat_aggregate_fwd_kernel<4, false, false>), grid, block, 0, s, a);
+      TV_GAT_LAUNCH(gat_aggregate_fwd_kernel, grid, block, 0, s, a, , false, false);
     }
   }
   TV_LAUNCH_CHECK("tv_gat_aggregate_fwd");
@@ -597,15 +615,13 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
     int64_t blocks = tv_cdiv(rows, TV_STAT_WAVES);
     if (blocks > 2048) blocks = 2048;
     const dim3 grid((unsigned)blocks), block(64 * TV_STAT_WAVES);
-    if (big) hipLaunchKernelGGL((gat_bwd_edge_kernel<8>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gat_bwd_edge_kernel<4>), grid, block, 0, s, a);
+    TV_GAT_LAUNCH(gat_bwd_edge_kernel, grid, block, 0, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(edge)");
   }
   {
     const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
     const size_t ldsb = sizeof(float) * 3 * HF;
-    if (big) hipLaunchKernelGGL((gat_bwd_node_kernel<8>), grid, block, ldsb, s, a);
-    else hipLaunchKernelGGL((gat_bwd_node_kernel<4>), grid, block, ldsb, s, a);
+    TV_GAT_LAUNCH(gat_bwd_node_kernel, grid, block, ldsb, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(node)");
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(tv_slot_grid(3 * HF)), dim3(256), 0, s,
