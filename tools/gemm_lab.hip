@@ -235,6 +235,31 @@ void run(const char *name, const float *A, const float *B, float *C, int M, int 
   printf("%-44s M=%6d N=%5d K=%5d wg=%5d  %8.3f ms  %7.1f TF\n", name, M, N, K, nwg, ms, 2.0 * M * N * K / ms / 1e9);
 }
 
+extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
+                           int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc,
+                           const float *bias, const float *row_scale, int accumulate, void *workspace,
+                           int64_t workspace_bytes, void *stream);
+extern "C" int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k);
+
+// the production kernel on the same buffers (NT)
+void run_lib(const char *name, const float *A, const float *B, float *C, int M, int N, int K) {
+  const int64_t wsb = tv_gemm_f32_workspace_bytes(M, N, K);
+  void *ws = nullptr;
+  if (wsb) CHECK(hipMalloc(&ws, wsb));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) tv_gemm_f32(0, 1, M, N, K, A, K, B, K, C, N, nullptr, nullptr, 0, ws, wsb, nullptr);
+  CHECK(hipDeviceSynchronize());
+  const int reps = 20;
+  CHECK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) tv_gemm_f32(0, 1, M, N, K, A, K, B, K, C, N, nullptr, nullptr, 0, ws, wsb, nullptr);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+  printf("%-44s M=%6d N=%5d K=%5d ws=%4lld MB %8.3f ms  %7.1f TF\n", name, M, N, K, (long long)(wsb >> 20), ms, 2.0 * M * N * K / ms / 1e9);
+  if (ws) CHECK(hipFree(ws));
+}
+
 int main() {
   const int shapes[][3] = {{51200, 1024, 1024}, {4096, 4096, 4096}, {49152, 1024, 1024}, {1024, 1024, 51200}};
   for (auto &s : shapes) {
@@ -248,6 +273,7 @@ int main() {
     CHECK(hipMemcpy(B, h.data() + 17, (size_t)N * K * 4 - 68, hipMemcpyHostToDevice));
     run<0, 2>("v1 baseline NT", A, B, C, M, N, K);
     run2<false, false>("v2 NT (A [M][K], B [N][K])", A, B, C2, M, N, K);
+    run_lib("library tv_gemm_f32 NT", A, B, C2, M, N, K);
     CHECK(hipMemset(d, 0, 4));
     hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, 0, C, C2, (size_t)M * N, d);
     float hd; CHECK(hipMemcpy(&hd, d, 4, hipMemcpyDeviceToHost));

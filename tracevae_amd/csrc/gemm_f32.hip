@@ -67,7 +67,11 @@ template <bool KX, bool VEC>
 struct Stage {
   static constexpr int NL = VEC ? 4 : 16;
   float r[16];
-  unsigned off[NL];   // element offset of each load from the tile origin, x clamped into range
+  // element offset of load i from the tile origin = min(off0 + i*step, offmax): consecutive
+  // loads of a thread are `step` apart (a multiple of ld), and offmax clamps an out-of-range x
+  // (rows of an [x][k] operand) onto the last valid row -- such an x only feeds accumulators
+  // that are never stored, it just has to read a valid element
+  unsigned off0, offmax, step;
   const float *tile;  // origin of the current tile (wave-uniform)
   int64_t ld;
   int t;
@@ -80,17 +84,25 @@ struct Stage {
     if (VEC) return KX ? (t & 31) * 4 : (t >> 3) + 32 * i;
     return KX ? (t & 127) : (t >> 5) + 8 * i;
   }
+  __device__ __forceinline__ unsigned offset(int i) const {
+    const unsigned o = off0 + (unsigned)i * step;
+    return KX ? o : (o < offmax ? o : offmax);
+  }
 
   __device__ __forceinline__ void init(const float *base, int64_t ld_, int64_t x0, int64_t xlim,
                                        int64_t k0, int t_) {
     ld = ld_; t = t_;
     tile = KX ? base + k0 * ld + x0 : base + x0 * ld + k0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      int x = xlocal(i);
-      // an out-of-range x only feeds accumulators that are never stored: read a valid element
-      if (x0 + x + (VEC && KX ? 3 : 0) >= xlim) x = (VEC && KX) ? 0 : (int)(xlim - 1 - x0);
-      off[i] = KX ? (unsigned)(klocal(i) * ld + x) : (unsigned)(x * ld + klocal(i));
+    if (KX) {
+      int x = xlocal(0);
+      if (x0 + x + (VEC ? 3 : 0) >= xlim) x = VEC ? 0 : (int)(xlim - 1 - x0);
+      off0 = (unsigned)(klocal(0) * ld + x);
+      step = (unsigned)((VEC ? 8 : 2) * ld);
+      offmax = 0xffffffffu;
+    } else {
+      off0 = (unsigned)(xlocal(0) * ld + klocal(0));
+      step = (unsigned)((VEC ? 32 : 8) * ld);
+      offmax = (unsigned)((xlim - 1 - x0) * ld + klocal(0));
     }
   }
 
@@ -101,10 +113,10 @@ struct Stage {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       if (VEC) {
-        const float4 v = *reinterpret_cast<const float4 *>(tile + off[i]);
+        const float4 v = *reinterpret_cast<const float4 *>(tile + offset(i));
         r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
       } else {
-        r[i] = tile[off[i]];
+        r[i] = tile[offset(i)];
       }
     }
   }
@@ -115,7 +127,7 @@ struct Stage {
     for (int i = 0; i < NL; ++i) {
       const int kl = klocal(i);
       const bool ok = kl < rem;
-      const unsigned o = ok ? off[i] : off[i] - (KX ? (unsigned)(kl * ld) : (unsigned)kl);
+      const unsigned o = ok ? offset(i) : offset(i) - (KX ? (unsigned)(kl * ld) : (unsigned)kl);
       if (VEC) {
         const float4 v = *reinterpret_cast<const float4 *>(tile + o);
         r[4 * i] = ok ? v.x : 0.f; r[4 * i + 1] = ok ? v.y : 0.f;
@@ -150,6 +162,32 @@ __device__ __forceinline__ void read_fragments(const float *s, int w64, int lane
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) f[sub][q] = s[(8 * kb + 4 * kh + q) * SK + w64 + sub * 32 + xl];
+    }
+  }
+}
+
+// acc += A-tile . B-tile over `nkb` k-blocks of 8 (FULL: all four, fragments of block kb+1 are
+// read while block kb is multiplied)
+template <bool A_KX, bool B_KX, bool FULL>
+__device__ __forceinline__ void multiply_tile(const float *as, const float *bs, int wm64, int wn64,
+                                              int lane, int nkb, f32x16 (&acc)[2][2]) {
+  float fa[2][2][4], fb[2][2][4];
+  read_fragments<A_KX>(as, wm64, lane, 0, fa[0]);
+  read_fragments<B_KX>(bs, wn64, lane, 0, fb[0]);
+#pragma unroll
+  for (int kb = 0; kb < BK / 8; ++kb) {
+    if (!FULL && kb >= nkb) break;
+    const int c = kb & 1;
+    if (kb + 1 < BK / 8 && (FULL || kb + 1 < nkb)) {
+      read_fragments<A_KX>(as, wm64, lane, kb + 1, fa[c ^ 1]);
+      read_fragments<B_KX>(bs, wn64, lane, kb + 1, fb[c ^ 1]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][s], fb[c][0][s], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][s], fb[c][1][s], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][0][s], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][1][s], acc[1][1], 0, 0, 0);
     }
   }
 }
@@ -223,7 +261,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     if (ntf > 1) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
   }
 
-  for (int it = 0; it < nt; ++it) {
+  // steady state: tiles t, t+1 and t+2 are all full k-tiles, nothing is conditional
+  int it = 0;
+  for (; it + 2 < ntf; ++it) {
+    const int cur = it & 1;
+    __syncthreads();
+    sa.store(As + (cur ^ 1) * TILE_FLOATS);
+    sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
+    sa.advance(); sb.advance();
+    sa.load(); sb.load();
+    multiply_tile<A_KX, B_KX, true>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
+                                    lane, BK / 8, acc);
+  }
+  // the last (up to three) tiles: stop staging, the partial k-tile goes through the masked path
+  for (; it < nt; ++it) {
     const int cur = it & 1;
     __syncthreads();
     if (it + 1 < nt) {
@@ -234,25 +285,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
       sa.advance(); sb.advance();
       if (it + 2 < ntf) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
     }
-    const float *as = As + cur * TILE_FLOATS, *bs = Bs + cur * TILE_FLOATS;
-    float fa[2][2][4], fb[2][2][4];
-    read_fragments<A_KX>(as, wm * 64, lane, 0, fa[0]);
-    read_fragments<B_KX>(bs, wn * 64, lane, 0, fb[0]);
-#pragma unroll
-    for (int kb = 0; kb < BK / 8; ++kb) {
-      const int c = kb & 1;
-      if (kb + 1 < BK / 8) {
-        read_fragments<A_KX>(as, wm * 64, lane, kb + 1, fa[c ^ 1]);
-        read_fragments<B_KX>(bs, wn * 64, lane, kb + 1, fb[c ^ 1]);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][s], fb[c][0][s], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][s], fb[c][1][s], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][0][s], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][1][s], acc[1][1], 0, 0, 0);
-      }
-    }
+    // only the k-blocks (8 deep) that hold data: all four, fewer in the partial tile
+    multiply_tile<A_KX, B_KX, false>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
+                                     lane, it < ntf ? BK / 8 : (rem + 7) >> 3, acc);
   }
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -273,6 +308,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   float *out = split ? (g.slabs + (int64_t)sp * g.M * g.N) : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
   const bool plain = split || (!g.row_scale && !g.accumulate);
+  if (plain && m0 + BM <= g.M && n0 + BN <= g.N) {
+    // interior tile: unchecked stores
+    float *o = out + (m0 + wm * 64 + 4 * kh) * ldo + n0 + wn * 64 + xl;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float bv = (!split && g.bias) ? g.bias[n0 + wn * 64 + j * 32 + xl] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32] = acc[i][j][r] + bv;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
