@@ -239,7 +239,7 @@ def main():
             'roofline': roof, 'other_kernels': others, 'scoring': scoring,
             'final_loss': float(loss_vals[-1]),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
             threads = min(16, os.cpu_count() or 1)
             line['cpu_baseline'] = cpu_baseline(cfg, flat, lr, V, M, args.cpu_baseline_traces, threads)
         print(json.dumps(line), flush=True)
