@@ -117,13 +117,23 @@ def cpu_baseline(cfg, flat, lr, V, M, n_traces, threads):
 
 def main():
     args = parse_args()
+    if os.environ.get('TRACEVAE_BENCH_WATCHDOG'):      # debugging aid: dump all stacks and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['TRACEVAE_BENCH_WATCHDOG']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # one process per GPU over RCCL; TRACEVAE_DIST_BACKEND=gloo rehearses the N > 1 control
+        # flow on a box with fewer GPUs than ranks (ranks then share devices)
+        backend = os.environ.get('TRACEVAE_DIST_BACKEND', 'nccl')
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -176,7 +186,8 @@ def main():
             print(f'gemm m={m:7d} n={n:5d} k={k:7d} ta={int(ta)} tb={int(tb)}  x{cnt / args.steps:5.1f}/step '
                   f'{ms / args.steps:7.3f} ms/step  {work / ms / 1e9:6.1f} TF', file=sys.stderr)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_vals = torch.stack(losses).cpu().numpy()

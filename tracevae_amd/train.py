@@ -269,8 +269,13 @@ class Trainer(object):
         if backend == 'nccl':   # RCCL over xGMI
             dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg)
         else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-            g.div_(self.world_size)
+            # gloo (CPU tests, rehearsals): stage through the host, gloo's device path is not
+            # dependable on ROCm
+            h = g.detach().cpu() if g.is_cuda else g
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            h.div_(self.world_size)
+            if g.is_cuda:
+                g.copy_(h)
 
 
 def save_model(vae: TraceVAE, config: ExpConfig, out_dir: str, name: str = 'final') -> str:
