@@ -199,3 +199,53 @@ def test_store_stream_shards_batches_across_ranks():
         seen += ids
     allids = np.concatenate(seen)
     assert sorted(allids.tolist()) == list(range(103))        # a partition of the data set
+
+
+def test_analyze_anomaly_nll_matches_reference_vectors():
+    """`analyze_anomaly_nll` / `best_fscore` against the reference's own functions
+    (fixture tests/golden/analyze_nll_vectors.json, generator make_analyze_vectors.py)."""
+    import json
+    import math
+    from tracevae_amd.evaluation import analyze_anomaly_nll
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                        'analyze_nll_vectors.json')
+    with open(path) as f:
+        cases = json.load(f)['cases']
+    assert len(cases) >= 4
+    for c in cases:
+        got = analyze_anomaly_nll(np.array(c['nll']), np.array(c['labels']), threshold=c['threshold'])
+        assert set(got) == set(c['result'])
+        for k, want in c['result'].items():
+            assert got[k] == want or (math.isnan(want) and math.isnan(got[k])), k
+    # an absent class gives NaN metrics, not an exception (the reference's log_error wrapper)
+    r = analyze_anomaly_nll(np.arange(6.0), np.array([0, 0, 0, 0, 1, 1]))
+    assert math.isnan(r['nll_latency']) and r['best_fscore_drop'] == 1.0 and 'fscore' not in r
+
+
+def test_threshold_std_limit_and_bias_std_inference():
+    """test.py:208-262 restated: known answers on hand-made inputs."""
+    from tracevae_amd.test import infer_bias_std, infer_std_limit, infer_threshold
+    # bias_std: a plain percentile
+    assert infer_bias_std(np.arange(1001.0), 0.995) == pytest.approx(995.0)
+    # threshold: constant scores -> that constant times amplify; clipped scores are dropped
+    assert infer_threshold(np.full(50, 7.0), 0.9, 2.0, 100_000, np.random.RandomState(0)) == 14.0
+    nll = np.concatenate([np.full(90, 3.0), np.full(10, 100_000.0)])
+    assert infer_threshold(nll, 0.995, 1.0, 100_000, np.random.RandomState(1)) == 3.0
+    nll = np.concatenate([np.full(90, 3.0), np.full(10, np.inf)])
+    assert infer_threshold(nll, 0.995, 1.0, None, np.random.RandomState(1)) == 3.0
+    # the same bootstrap as the reference's loop, drawn from an identical generator
+    scores = np.random.RandomState(5).normal(10, 2, size=400)
+    r1, r2 = np.random.RandomState(9), np.random.RandomState(9)
+    cand = []
+    for _ in range(10):
+        sub = r2.choice(scores, replace=True, size=len(scores))
+        sub = sub[sub < 100_000 - 1e-7]
+        cand.append(np.percentile(sub, 99.5) * 1.5)
+    assert infer_threshold(scores, 0.995, 1.5, 100_000, r1) == float(np.median(cand))
+    # std limit: per operation percentile * amplify, unseen operations take the maximum
+    op = np.array([0, 0, 0, 2, 2, 3])
+    sd = np.array([1.0, 2.0, 3.0, 10.0, 20.0, 0.5], dtype=np.float32)
+    lim = infer_std_limit(op, sd, 5, std_limit_p=1.0, std_limit_amplify=2.0)
+    assert lim.dtype == np.float32 and lim.tolist() == [6.0, 40.0, 40.0, 1.0, 40.0]
+    assert infer_std_limit(op, sd, 3, std_limit_fixed=0.25).tolist() == [0.25] * 3
+    assert infer_std_limit(op, sd, 2, std_limit_p=0.5, std_limit_global=True).tolist() == [2.5] * 2

@@ -254,3 +254,51 @@ def test_compact_latency_decoder_equals_padded(device, monkeypatch, training):
         for n, want in b['grads'].items():
             scale = max(float(want.abs().max()), 1e-4 * gmax)
             assert float((a['grads'][n] - want).abs().max()) / scale < 1e-3, n
+
+
+def test_evaluate_nll_flow_thresholds_and_std_limit(device, tmp_path):
+    """test.py's evaluate-nll flow end to end on synthetic train / val / test sets: the K=1
+    collection passes, bias_std / threshold / per-operation std-limit inference, and the
+    K-sample test pass that uses them; the collected per-node values equal what the chain's
+    reference-style accessors give."""
+    import tracevae_amd.test as T
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    from tracevae_amd.evaluation import DeviceCollector, do_evaluate_nll, eval_step
+    from tracevae_amd.train import StoreStream
+    V, M = 40, 16
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 2, 24, seed=13)
+    vae.eval()
+    val_flat, _ = make_flat(20, V, M, seed=31)
+    test_flat, _ = make_flat(30, V, M, seed=32, anomaly_ratio=0.4)
+    val_store, test_store = DeviceTraceStore(val_flat, lr, V), DeviceTraceStore(test_flat, lr, V)
+    stream = lambda st: StoreStream(st, 7, max_node_count=M)
+    torch.manual_seed(0)
+    out_file = str(tmp_path / 'nll' / 'test.npz')
+    res = T.evaluate_nll(vae, stream(test_store), stream(store), stream(val_store), nll_out=out_file,
+                         n_z=3, infer_bias_std_=True, infer_threshold_=True, use_std_limit=True,
+                         std_limit_amplify=1.5, rng=np.random.RandomState(3))
+    assert {'train_nll_normal', 'val_nll_normal', 'test_auc', 'test_fscore', 'bias_std',
+            'train_threshold', 'val_threshold', 'test_test_loss', 'std_limit'} <= set(res)
+    assert res['std_limit'].shape == (V,) and np.isfinite(res['std_limit']).all()
+    assert vae.config.latency.decoder.biased_normal_std_threshold == res['bias_std']
+    saved = np.load(out_file)
+    assert saved['nll_list'].shape == (30,) and np.array_equal(saved['label_list'], test_flat.labels)
+    assert np.allclose(saved['anomaly_degree'] * res['test_best_threshold_latency'], saved['nll_list'])
+    # collectors == accessors (one batch, sample 0, real nodes in trace order)
+    G = TraceGraphBatch.from_store(val_store, np.arange(5), M)
+    g = torch.Generator().manual_seed(1)
+    eps = {'z': torch.randn(1, 5, 10, generator=g), 'z2': torch.randn(1, 5, 10, generator=g)}
+    _, _, chain = eval_step(vae, G, 1, eps=eps, return_chain=True, use_biased=False,
+                            latency_log_prob_weight=True)
+    base = chain.p['latency'].distribution.base_distribution
+    std, mean = base.std[0, ..., 0].cpu().numpy(), base.mean[0, ..., 0].cpu().numpy()
+    cnt = G.build_dgl().node_count.cpu().numpy()
+    want_std = np.concatenate([std[i, :k] for i, k in enumerate(cnt)])
+    col = DeviceCollector('x_')
+    col.add(base.std[0, ..., 0], G.build_dgl().node_count, np.zeros(5, np.int64))
+    assert np.array_equal(col.array('x_normal'), want_std) and len(col.array('x_drop')) == 0
+    # per-operation limit of an operation = amplify * percentile of its collected std
+    lim = T.infer_std_limit(G.build_dgl().node_type.cpu().numpy(), want_std, V, 0.99, 1.5)
+    op = int(G.build_dgl().node_type[0])
+    sel = G.build_dgl().node_type.cpu().numpy() == op
+    assert lim[op] == np.float32(1.5 * float(np.percentile(want_std[sel], 99.0)))

@@ -7,6 +7,9 @@ eval-mode BatchNorm is per row), then `tv_score_reduce`: sgvb loss and
 `nll = -log mean_k exp(log p(x,z_k) - log q(z_k|x))`, both clipped at `clip_nll`
 (NaN -> clip).  Scoring shards by trace with no communication.
 """
+import math
+import os
+import warnings
 from typing import Dict, Iterable, List, Optional
 
 import numpy as np
@@ -15,7 +18,8 @@ import torch
 from .batch import TraceGraphBatch
 from .model import TraceVAE
 
-__all__ = ['eval_step', 'do_evaluate_nll', 'analyze_anomaly_nll']
+__all__ = ['eval_step', 'do_evaluate_nll', 'analyze_anomaly_nll', 'best_fscore',
+           'fscore_for_precision_and_recall', 'DeviceCollector']
 
 
 @torch.no_grad()
@@ -35,73 +39,179 @@ def eval_step(vae: TraceVAE, G: TraceGraphBatch, n_z: int, *, use_biased: bool =
     return loss, nll
 
 
-def analyze_anomaly_nll(nll_list: np.ndarray, label_list: np.ndarray) -> Dict[str, float]:
-    """AUC / best-F1 of the scores per anomaly class (utils/analyze_nll.py:62-110,
-    utils/fscore_utils.py:28-37); classes that are absent are skipped."""
-    from sklearn.metrics import average_precision_score, precision_recall_curve, roc_auc_score
-    out: Dict[str, float] = {}
-    nll_list = np.asarray(nll_list, dtype=np.float64)
+def fscore_for_precision_and_recall(precision, recall) -> np.ndarray:
+    """utils/fscore_utils.py:13-26 (log-domain harmonic mean, 0 where either is 0)."""
+    precision = np.asarray(precision, dtype=np.float64)
+    recall = np.asarray(recall, dtype=np.float64)
+    return np.where(
+        (precision == 0) | (recall == 0), 0.0,
+        2. * np.exp(np.log(np.maximum(precision, 1e-8)) + np.log(np.maximum(recall, 1e-8)) -
+                    np.log(np.maximum(precision + recall, 1e-8))))
+
+
+def best_fscore(proba, truth):
+    """(f-score, threshold, precision, recall) at the best point of the PR curve
+    (utils/fscore_utils.py:29-34)."""
+    from sklearn.metrics import precision_recall_curve
+    precision, recall, threshold = precision_recall_curve(truth, proba)
+    fscore = fscore_for_precision_and_recall(precision, recall)
+    idx = int(np.argmax(fscore[:-1]))
+    return fscore[idx], threshold[idx], precision[idx], recall[idx]
+
+
+def analyze_anomaly_nll(nll_list: np.ndarray, label_list: np.ndarray,
+                        threshold: Optional[float] = None) -> Dict[str, float]:
+    """The score summary of `do_evaluate_nll` (utils/analyze_nll.py:62-110): mean NLL per class
+    (0 normal, 1 structure anomaly "drop", 2 latency anomaly), `auc` (which the reference
+    computes as AVERAGE PRECISION, fscore_utils.py:37-38), best F-score / precision / recall
+    over all anomalies and per class (the other anomaly class removed), and the F-scores at
+    `threshold` when one is given.  Pinned against the reference's own functions by
+    tests/golden/analyze_nll_vectors.json.  A failing metric (an absent class) is NaN, as the
+    reference's `log_error` wrapper makes it."""
+    from sklearn.metrics import average_precision_score, f1_score
+    nll_list = np.asarray(nll_list)
     label_list = np.asarray(label_list)
-    normal = nll_list[label_list == 0]
-    if len(normal):
-        out['nll_normal'] = float(np.mean(normal))
-    for tag, sel in (('', label_list != 0), ('_drop', label_list == 1), ('_latency', label_list == 2)):
-        pos = nll_list[sel]
-        if len(pos) == 0 or len(normal) == 0:
-            continue
-        if tag:
-            out[f'nll{tag}'] = float(np.mean(pos))
-        y = np.concatenate([np.zeros(len(normal)), np.ones(len(pos))])
-        s = np.concatenate([normal, pos])
-        out[f'auc{tag}'] = float(roc_auc_score(y, s))
-        out[f'ap{tag}'] = float(average_precision_score(y, s))
-        precision, recall, thresholds = precision_recall_curve(y, s)
-        f1 = 2 * precision * recall / np.maximum(precision + recall, 1e-12)
-        best = int(np.argmax(f1[:-1])) if len(f1) > 1 else 0
-        out[f'best_fscore{tag}'] = float(f1[best])
-        out[f'best_threshold{tag}'] = float(thresholds[best]) if len(thresholds) else float('nan')
+    is_anomaly = label_list != 0
+    nan4 = (math.nan, math.nan, math.nan, math.nan)
+
+    def guarded(fn, default, *args):
+        try:
+            return fn(*args)
+        except Exception:
+            return default
+
+    def mean_of(mask):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return float(np.mean(nll_list[mask])) if len(nll_list) else math.nan
+
+    out: Dict[str, float] = {
+        'nll_normal': mean_of(label_list == 0),
+        'nll_drop': mean_of(label_list == 1),
+        'nll_latency': mean_of(label_list == 2),
+    }
+    out['auc'] = guarded(lambda: float(average_precision_score(is_anomaly, nll_list)), math.nan)
+
+    def best_for_label(label):
+        mask = label_list != (2 if label == 1 else 1)
+        return guarded(best_fscore, nan4, nll_list[mask], label_list[mask] != 0)
+
+    f_t, _, pr_t, rc_t = guarded(best_fscore, nan4, nll_list, is_anomaly)
+    f_d, _, pr_d, rc_d = best_for_label(1)
+    f_l, th_l, pr_l, rc_l = best_for_label(2)
+    out.update({
+        'best_fscore': float(f_t), 'best_fscore_drop': float(f_d), 'best_fscore_latency': float(f_l),
+        'best_pr': float(pr_t), 'best_rc': float(rc_t),
+        'best_pr_drop': float(pr_d), 'best_rc_drop': float(rc_d),
+        'best_pr_latency': float(pr_l), 'best_rc_latency': float(rc_l),
+        'best_threshold_latency': float(th_l),
+    })
+    if threshold is not None:
+        def f_at(label):
+            mask = label_list != (2 if label == 1 else 1)
+            return guarded(f1_score, math.nan, label_list[mask] != 0, nll_list[mask] > threshold)
+        out.update({
+            'fscore': float(guarded(f1_score, math.nan, is_anomaly, nll_list > threshold)),
+            'fscore_drop': float(f_at(1)), 'fscore_latency': float(f_at(2)),
+        })
     return out
+
+
+class DeviceCollector(object):
+    """The `ArrayBuffer` collectors of the reference (evaluation.py:76-99, filled by
+    tensor_utils.py:139-225), kept on the GPU: per category (`normal` / `drop` / `latency`, by
+    trace label) the per-node values of the real nodes of sample 0.  `.array(key)` makes the
+    one device->host copy."""
+
+    CATEGORIES = ((0, 'normal'), (1, 'drop'), (2, 'latency'))
+
+    def __init__(self, prefix: str = ''):
+        self.prefix = prefix
+        self.chunks: Dict[str, List[torch.Tensor]] = {}
+
+    def add(self, values_bm: torch.Tensor, node_count: torch.Tensor, labels: np.ndarray) -> None:
+        """values_bm [B, M]; rows of real nodes (slot < node_count) are kept, in trace order."""
+        b, m = values_bm.shape
+        real = torch.arange(m, device=values_bm.device)[None, :] < node_count[:, None]
+        lab = torch.as_tensor(np.asarray(labels), device=values_bm.device)
+        for code, name in self.CATEGORIES:
+            sel = real & (lab == code)[:, None]
+            self.chunks.setdefault(self.prefix + name, []).append(values_bm[sel])
+
+    def array(self, key: str) -> np.ndarray:
+        parts = self.chunks.get(key, [])
+        return torch.cat(parts).cpu().numpy() if parts else np.zeros([0], np.float32)
 
 
 def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: int,
                     use_biased: bool = True, use_latency_biased: bool = True,
                     no_latency: bool = False, std_limit=None, latency_log_prob_weight: bool = False,
                     latency_logstd_min: Optional[float] = None, clip_nll: Optional[float] = None,
+                    test_threshold: Optional[float] = None,
                     nll_output_file: Optional[str] = None, labels: Optional[np.ndarray] = None,
+                    operation_id_dict_out: Optional[DeviceCollector] = None,
+                    latency_std_dict_out: Optional[DeviceCollector] = None,
+                    latency_reldiff_dict_out: Optional[DeviceCollector] = None,
                     **_ignored) -> Dict[str, float]:
-    """The scoring driver: score every batch of the stream, keep the scores on the GPU until
-    the end (one device->host copy), then the AUC / F1 summary and the optional `.npz`
-    (evaluation.py:249-283).  The plotting / collector options of the reference are
-    diagnostics and not part of this path; they are accepted and ignored."""
+    """The scoring driver (evaluation.py:40-283): score every batch of the stream, keep scores
+    and collected per-node values on the GPU until the end (one device->host copy each), then
+    the summary of `analyze_anomaly_nll` and the optional `.npz` (`nll_list`, `label_list`,
+    `anomaly_degree = nll / best_threshold_latency`, evaluation.py:276-283).  The three
+    collectors feed test.py's std-limit / bias-std inference (operation id, predicted latency
+    std and |latency - mean| / std of every real node, by trace label).  The plotting and
+    p_node_count / p_edge collectors of the reference are diagnostics outside this path:
+    accepted and ignored."""
     was_training = vae.training
     vae.eval()
     nll_chunks: List[torch.Tensor] = []
     loss_chunks: List[torch.Tensor] = []
+    weights: List[int] = []
     label_chunks: List[np.ndarray] = []
+    collect = any(c is not None for c in (operation_id_dict_out, latency_std_dict_out,
+                                         latency_reldiff_dict_out)) and not no_latency
+    offset = 0
     try:
         for G in test_stream:
-            loss, nll = eval_step(
+            res = eval_step(
                 vae, G, n_z, use_biased=use_biased, use_latency_biased=use_latency_biased,
                 no_latency=no_latency, std_limit=std_limit,
                 latency_log_prob_weight=latency_log_prob_weight,
-                latency_logstd_min=latency_logstd_min, clip_nll=clip_nll)
+                latency_logstd_min=latency_logstd_min, clip_nll=clip_nll, return_chain=collect)
+            loss, nll = res[0], res[1]
             nll_chunks.append(nll)
-            loss_chunks.append(loss)
-            if labels is None and G.labels is not None:
-                label_chunks.append(G.labels)
+            loss_chunks.append(loss.mean().reshape(1))
+            weights.append(len(nll))
+            step_labels = labels[offset:offset + len(nll)] if labels is not None else G.labels
+            if step_labels is None:
+                step_labels = np.zeros(len(nll), np.int64)
+            label_chunks.append(np.asarray(step_labels))
+            offset += len(nll)
+            if collect:
+                chain, batch = res[2], G.build_dgl()
+                count = batch.node_count
+                if operation_id_dict_out is not None:
+                    operation_id_dict_out.add(batch.node_type_pad, count, step_labels)
+                base = chain.p['latency'].distribution.base_distribution
+                std = base.std[0, ..., 0]
+                if latency_std_dict_out is not None:
+                    latency_std_dict_out.add(std, count, step_labels)
+                if latency_reldiff_dict_out is not None:
+                    rel = (batch.latency_pad[..., 0] - base.mean[0, ..., 0]) / std.clamp(min=1e-7)
+                    latency_reldiff_dict_out.add(rel.abs(), count, step_labels)
     finally:
         vae.train(was_training)
     nll_list = torch.cat(nll_chunks).cpu().numpy() if nll_chunks else np.zeros([0], np.float32)
-    loss_list = torch.cat(loss_chunks).cpu().numpy() if loss_chunks else np.zeros([0], np.float32)
-    if labels is None:
-        labels = np.concatenate(label_chunks) if label_chunks else np.zeros(len(nll_list), np.int64)
+    label_list = np.concatenate(label_chunks) if label_chunks else np.zeros([0], np.int64)
     result: Dict[str, float] = {}
-    normal_losses = loss_list[labels == 0]
-    if len(normal_losses):
-        result['test_loss'] = float(np.nanmean(normal_losses))
-    result.update(analyze_anomaly_nll(nll_list, labels))
+    if loss_chunks:
+        # batch-size weighted mean of the per-batch mean losses (evaluation.py:247-260)
+        w = np.asarray(weights, dtype=np.float64)
+        result['test_loss'] = float(np.sum(torch.cat(loss_chunks).cpu().numpy() * (w / w.sum())))
+    result.update(analyze_anomaly_nll(nll_list, label_list, threshold=test_threshold))
     if nll_output_file is not None:
-        np.savez_compressed(nll_output_file, nll_list=nll_list, label_list=labels)
+        os.makedirs(os.path.dirname(os.path.abspath(nll_output_file)), exist_ok=True)
+        np.savez_compressed(nll_output_file, nll_list=nll_list, label_list=label_list,
+                            anomaly_degree=nll_list / result['best_threshold_latency'])
     result['_nll_list'] = nll_list
-    result['_label_list'] = labels
+    result['_label_list'] = label_list
     return result
