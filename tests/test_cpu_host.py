@@ -249,3 +249,21 @@ def test_threshold_std_limit_and_bias_std_inference():
     assert lim.dtype == np.float32 and lim.tolist() == [6.0, 40.0, 40.0, 1.0, 40.0]
     assert infer_std_limit(op, sd, 3, std_limit_fixed=0.25).tolist() == [0.25] * 3
     assert infer_std_limit(op, sd, 2, std_limit_p=0.5, std_limit_global=True).tolist() == [2.5] * 2
+
+
+def test_flat_dataset_files_round_trip(tmp_path):
+    """`data_process`: FlatTraces <-> .npz, and the concatenation of the three test sets."""
+    from helpers import make_flat
+    from tracevae_amd.data_process import concat_flat, load_flat, save_flat
+    a, _ = make_flat(5, 30, 12, seed=1)
+    b, _ = make_flat(3, 30, 12, seed=2, anomaly_ratio=1.0)
+    path = str(tmp_path / 'processed' / 'a.npz')
+    save_flat(path, a)
+    back = load_flat(path)
+    for f in ('node_offsets', 'u', 'v', 'node_type', 'avg_latency', 'max_latency', 'min_latency', 'labels'):
+        assert np.array_equal(getattr(back, f), getattr(a, f)) and getattr(back, f).dtype == getattr(a, f).dtype
+    both = concat_flat([a, b])
+    both.validate(12)
+    assert len(both) == 8 and int(both.node_offsets[-1]) == int(a.node_offsets[-1] + b.node_offsets[-1])
+    assert np.array_equal(both.node_type[int(a.node_offsets[-1]):], b.node_type)
+    assert np.array_equal(both.labels, np.concatenate([a.labels, b.labels]))

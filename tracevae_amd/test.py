@@ -14,6 +14,9 @@ sqlite data sets, plots).  What it keeps is the part that decides the numbers:
 The inference functions are NumPy restatements of those lines (host side, a few thousand
 values); the scoring passes run on the accelerated path.
 """
+import argparse
+import json
+import sys
 from typing import Dict, Iterable, Optional
 
 import numpy as np
@@ -22,7 +25,7 @@ from .batch import TraceGraphBatch
 from .evaluation import DeviceCollector, do_evaluate_nll
 from .model import TraceVAE
 
-__all__ = ['infer_bias_std', 'infer_threshold', 'infer_std_limit', 'evaluate_nll']
+__all__ = ['infer_bias_std', 'infer_threshold', 'infer_std_limit', 'evaluate_nll', 'main']
 
 
 def infer_bias_std(val_normal_reldiff: np.ndarray, bias_std_normal_p: float = 0.995) -> float:
@@ -135,3 +138,74 @@ def evaluate_nll(vae: TraceVAE, test_stream: Iterable[TraceGraphBatch],
     run(test_stream, 'test', n_z, thresholds.get('val_threshold'), std_group_limit, nll_out)
     results['std_limit'] = std_group_limit
     return results
+
+
+def main(argv=None) -> int:
+    """`python -m tracevae_amd.test evaluate-nll -M <model dir|.pt> -D <dataset> [flags]`: the
+    options of test.sh / test.py:58-84 (plot outputs are not produced)."""
+    import torch
+    from .batch import DeviceTraceStore
+    from .data_process import TEST_SETS, concat_flat, load_dataset
+    from .train import StoreStream, load_model
+    ap = argparse.ArgumentParser(prog='tracevae_amd.test')
+    sub = ap.add_subparsers(dest='command', required=True)
+    p = sub.add_parser('evaluate-nll')
+    p.add_argument('-D', '--data-dir')
+    p.add_argument('-M', '--model-path', required=True)
+    p.add_argument('-o', '--nll-out')
+    p.add_argument('--device')
+    p.add_argument('--n_z', type=int, default=10)
+    p.add_argument('--batch-size', type=int, default=128)
+    p.add_argument('--clip-nll', type=float, default=100_000)
+    for flag in ('--no-biased', '--no-latency-biased', '--no-latency', '--use-train-val',
+                 '--infer-bias-std', '--infer-threshold', '--no-latency-log-prob-weight',
+                 '--use-std-limit', '--std-limit-global'):
+        p.add_argument(flag, action='store_true')
+    p.add_argument('--bias-std-normal-p', type=float, default=0.995)
+    p.add_argument('--threshold-p', type=float, default=0.995)
+    p.add_argument('--threshold-amplify', type=float, default=1.0)
+    p.add_argument('--std-limit-fixed', type=float, default=None)
+    p.add_argument('--std-limit-p', type=float, default=0.99)
+    p.add_argument('--std-limit-amplify', type=float, default=1.0)
+    args, extra = ap.parse_known_args(argv)
+    if not torch.cuda.is_available():
+        from . import hip
+        raise hip.HipLibraryError('the accelerated path needs a GPU (there is no CPU fallback); '
+                                  f'--device={args.device} cannot be honoured')
+    device = torch.device('cuda', torch.cuda.current_device())
+    # the data set root comes from the train config unless -D is given (test.py:108-109)
+    import os
+    cfg_dir = os.path.dirname(os.path.dirname(os.path.abspath(args.model_path))) \
+        if args.model_path.endswith('.pt') else args.model_path
+    data_dir = args.data_dir
+    if data_dir is None:
+        with open(os.path.join(cfg_dir, 'config.json'), 'r', encoding='utf-8') as f:
+            data_dir = json.load(f)['dataset']['root_dir']
+    sets, id_manager, latency_range = load_dataset(data_dir)
+    v = id_manager.num_operations
+    vae, _config = load_model(args.model_path, v, extra_args=extra, device=device)
+    store = lambda flat: DeviceTraceStore(flat, latency_range, v)
+    stream = lambda flat, shuffle: StoreStream(store(flat), args.batch_size, shuffle=shuffle)
+    need_tv = args.use_train_val or args.infer_bias_std or args.infer_threshold or args.use_std_limit
+    result = evaluate_nll(
+        vae, stream(concat_flat(sets[n] for n in TEST_SETS), False),
+        stream(sets['train'], True) if need_tv else None,
+        stream(sets['val'], True) if need_tv else None,
+        nll_out=args.nll_out, n_z=args.n_z, clip_nll=args.clip_nll, no_biased=args.no_biased,
+        no_latency_biased=args.no_latency_biased, no_latency=args.no_latency,
+        use_train_val=args.use_train_val, infer_bias_std_=args.infer_bias_std,
+        bias_std_normal_p=args.bias_std_normal_p, infer_threshold_=args.infer_threshold,
+        threshold_p=args.threshold_p, threshold_amplify=args.threshold_amplify,
+        no_latency_log_prob_weight=args.no_latency_log_prob_weight,
+        use_std_limit=args.use_std_limit, std_limit_global=args.std_limit_global,
+        std_limit_fixed=args.std_limit_fixed, std_limit_p=args.std_limit_p,
+        std_limit_amplify=args.std_limit_amplify)
+    limit = result.pop('std_limit')
+    if limit is not None:
+        result['std_limit_max'] = float(limit.max())
+    print(json.dumps(result, indent=1))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

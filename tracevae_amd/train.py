@@ -17,6 +17,8 @@ L2 / global-norm / clip / update three streaming kernels over the flat buffers
 import json
 import math
 import os
+import sys
+import time
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -29,7 +31,8 @@ from .config import ExpConfig, config_to_dict
 from .model import TraceVAE
 
 __all__ = ['NANLossError', 'FlatParameters', 'FlatOptimizer', 'compute_train_loss', 'Trainer',
-           'l2_parameter_names', 'learning_rate_for_epoch', 'save_model', 'StoreStream']
+           'l2_parameter_names', 'learning_rate_for_epoch', 'save_model', 'StoreStream', 'fit',
+           'load_model', 'main']
 
 
 class NANLossError(Exception):
@@ -207,7 +210,7 @@ class Trainer(object):
         self.part_names = part
         start = f.tail_start if latency_only else 0
         self.optimizer = FlatOptimizer(f, self.train_cfg.optimizer, start, f.total)
-        self.optimizer.set_lr(learning_rate_for_epoch(self.train_cfg, self.epoch))
+        self.optimizer.set_lr(learning_rate_for_epoch(self.train_cfg, self.epoch - 1))
         self.l2_names = l2_parameter_names(f.all_names, part)
         self.l2_mask = f.mask(self.l2_names)
         self._l2_partial = torch.empty(hip.query('tv_reduce_blocks', f.total), dtype=torch.float64,
@@ -224,8 +227,11 @@ class Trainer(object):
             self.vae.train()
 
     def set_epoch(self, epoch: int) -> None:
+        """Epoch `epoch` (1-based) starts.  The reference sets the learning rate when the
+        previous epoch ends, from the count of finished epochs (train.py:374-383): epoch e
+        runs at initial_lr * ratio ** ((e - 1) // anneal_epochs)."""
         self.epoch = epoch
-        self.optimizer.set_lr(learning_rate_for_epoch(self.train_cfg, epoch))
+        self.optimizer.set_lr(learning_rate_for_epoch(self.train_cfg, epoch - 1))
 
     # -- one step ----------------------------------------------------------------------
     def l2_value(self) -> torch.Tensor:
@@ -315,3 +321,151 @@ class StoreStream(object):
         for i in range(self.rank, total, self.world_size):
             ids = order[i * self.batch_size:(i + 1) * self.batch_size]
             yield TraceGraphBatch.from_store(self.store, ids, self.max_node_count)
+
+
+# ---------------------------------------------------------------------------------------
+# the training job (train.py:100-500 without the mltk experiment / TensorBoard plumbing)
+# ---------------------------------------------------------------------------------------
+def load_model(model_path: str, num_operations: int, extra_args=(), device=None):
+    """`load_config` + `load_model2` (test_utils.py:22-100): `model_path` is the train output
+    directory (`config.json`, `models/final.pt`) or one `models/<name>.pt`."""
+    if model_path.endswith('.pt'):
+        model_file = model_path
+        config_file = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(model_path))),
+                                   'config.json')
+    else:
+        model_file = os.path.join(model_path, 'models', 'final.pt')
+        config_file = os.path.join(model_path, 'config.json')
+    from .config import config_from_dict, parse_flags
+    with open(config_file, 'r', encoding='utf-8') as f:
+        config = config_from_dict(ExpConfig(), json.load(f))
+    if extra_args:
+        parse_flags(config, list(extra_args), strict=False)
+    vae = TraceVAE(config.model, num_operations)
+    vae.load_state_dict(torch.load(model_file, map_location='cpu', weights_only=True))
+    if device is not None:
+        vae = vae.to(device)
+    return vae, config
+
+
+def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: int,
+        out_dir: str, rank: int = 0, world_size: int = 1, process_group=None,
+        log=print) -> Dict[str, float]:
+    """The two-phase training job: epochs 1..struct_pretrain_epochs move every parameter,
+    the rest only `latency_vae.*` with everything else in eval mode (train.py:455-487); the
+    learning rate is annealed per epoch; validation, periodic test scoring and a checkpoint
+    after every epoch; final K-sample scoring of the test sets and `models/final.pt`.
+    `stores`: 'train', 'val', 'test' (the three test sets concatenated).  With world_size > 1
+    rank r trains on batches r, r+W, ... of every epoch's permutation and rank 0 writes."""
+    from .evaluation import do_evaluate_nll
+    tc = config.train
+    if config.seed is not None:
+        torch.manual_seed(config.seed)
+        np.random.seed(config.seed)
+    device = stores['train'].device
+    vae = TraceVAE(config.model, num_operations).to(device)
+    if world_size > 1:
+        for t in list(vae.parameters()) + list(vae.buffers()):
+            dist.broadcast(t.data, 0, group=process_group)
+    trainer = Trainer(vae, config, world_size=world_size, process_group=process_group)
+    train_stream = StoreStream(stores['train'], tc.batch_size, shuffle=True,
+                               seed=config.seed or 0, rank=rank, world_size=world_size)
+    val_stream = StoreStream(stores['val'], tc.val_batch_size)
+    test_stream = StoreStream(stores['test'], config.test.batch_size)
+    result: Dict[str, float] = {}
+
+    def evaluate(n_z, tag):
+        r = do_evaluate_nll(test_stream, vae, n_z, use_biased=config.test.use_biased,
+                            latency_log_prob_weight=config.test.latency_log_prob_weight,
+                            clip_nll=config.test.clip_nll)
+        r = {k: v for k, v in r.items() if not k.startswith('_')}
+        if rank == 0:
+            path = os.path.join(out_dir, 'result', 'test-anomaly', f'{tag}.json')
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, 'w', encoding='utf-8') as f:
+                f.write(json.dumps(r))
+        return r
+
+    # data-dependent initialisation on one batch (train.py:188-199), in the training mode
+    trainer.apply_mode()
+    rng = np.random.RandomState(config.seed or 0)
+    init_ids = rng.choice(len(stores['train']), size=min(tc.init_batch_size, len(stores['train'])),
+                          replace=False)
+    with torch.no_grad():
+        G = TraceGraphBatch.from_store(stores['train'], init_ids)
+        loss = vae.q(G).chain(vae.p, G=G).vi.training.sgvb(reduction='mean')
+    log(f'Network initialized: loss = {float(loss):.6g}')
+
+    pretrain = tc.struct_pretrain_epochs if config.model.arch == 'default' else None
+    for epoch in range(1, tc.max_epoch + 1):
+        if pretrain and epoch == pretrain + 1:
+            trainer.epoch = epoch
+            trainer.set_phase(latency_only=True)
+            log(f'Start to train latency_vae with {len(trainer.part_names)} params ...')
+        trainer.set_epoch(epoch)
+        trainer.apply_mode()
+        t0, losses = time.perf_counter(), []
+        for G in train_stream:
+            losses.append(trainer.step(G)['loss'])
+        mean_loss = float(torch.stack(losses).mean()) if losses else float('nan')
+        msg = f'epoch {epoch}/{tc.max_epoch}: loss {mean_loss:.6g} ({time.perf_counter() - t0:.2f}s)'
+        if tc.val_epoch_freq and epoch % tc.val_epoch_freq == 0:
+            vae.eval()
+            with torch.no_grad():
+                vals = [vae.q(G).chain(vae.p, G=G).vi.training.sgvb().mean() for G in val_stream]
+            result['val_loss'] = float(torch.stack(vals).mean()) if vals else float('nan')
+            msg += f' val_loss {result["val_loss"]:.6g}'
+        log(msg)
+        if tc.test_epoch_freq and epoch % tc.test_epoch_freq == 0:
+            r = evaluate(tc.test_n_z, str(epoch))
+            log(f'  test: auc {r.get("auc", float("nan")):.4f} best_fscore '
+                f'{r.get("best_fscore", float("nan")):.4f}')
+        if rank == 0:
+            save_model(vae, config, out_dir, name=str(epoch))
+    vae.eval()
+    if rank == 0:
+        save_model(vae, config, out_dir, name='final')
+    result.update(evaluate(config.test.eval_n_z, 'final'))
+    result['_vae'] = vae
+    return result
+
+
+def main(argv=None) -> int:
+    """`python -m tracevae_amd.train --dataset.root_dir=<dir> [--a.b.c=value ...]`: the flags of
+    train.sh.  Output under ./results/train (config.json, models/<epoch>.pt, models/final.pt,
+    result/test-anomaly/*.json), like the reference's experiment directory."""
+    from .config import parse_flags
+    from .data_process import TEST_SETS, concat_flat, load_dataset
+    argv = list(sys.argv[1:] if argv is None else argv)
+    out_dir = 'results/train'
+    for a in list(argv):
+        if a.startswith('--output-dir='):
+            out_dir = a.split('=', 1)[1]
+            argv.remove(a)
+    config = ExpConfig()
+    parse_flags(config, argv)
+    if not torch.cuda.is_available():
+        raise hip.HipLibraryError('the accelerated path needs a GPU (there is no CPU fallback); '
+                                  f'--device={config.device} cannot be honoured')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
+        dist.init_process_group(os.environ.get('TRACEVAE_DIST_BACKEND', 'nccl'))
+    if config.device in (None, 'cpu') and rank == 0:
+        print(f'note: --device={config.device} ignored, running on cuda:{torch.cuda.current_device()}')
+    sets, id_manager, latency_range = load_dataset(config.dataset.root_dir)
+    v = id_manager.num_operations
+    stores = {'train': DeviceTraceStore(sets['train'], latency_range, v),
+              'val': DeviceTraceStore(sets['val'], latency_range, v),
+              'test': DeviceTraceStore(concat_flat(sets[n] for n in TEST_SETS), latency_range, v)}
+    result = fit(config, stores, v, out_dir, rank=rank, world_size=world)
+    if rank == 0:
+        print(json.dumps({k: val for k, val in result.items() if not k.startswith('_')}, indent=1))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
