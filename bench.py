@@ -228,6 +228,15 @@ def main():
                     'traffic_unit': 'bytes/launch (profiles/r01c_hbm_traffic.json)',
                     'launches': g[0], 'avg_ms': g[2] / max(g[0], 1),
                     'share_of_step': g[2] * 1e-3 / elapsed}
+            # the same figure for the shapes that carry the time (the aggregate above also
+            # holds the skinny K=40 / N=50 layers and the [512,10] MLP heads)
+            tags = sorted(ops.TIMER.by_tag('gemm_f32').items(), key=lambda kv: -kv[1][2])[:4]
+            roof['top_shapes'] = [
+                {'m': t[0], 'n': t[1], 'k': t[2], 'trans_a': t[3], 'trans_b': t[4],
+                 'launches_per_step': c / args.steps, 'ms_per_step': ms / args.steps,
+                 'achieved': w / (ms * 1e-3) / 1e12,
+                 'frac': w / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+                for t, (c, w, ms) in tags]
         others = {}
         for name in ('gat_aggregate_fwd', 'gat_aggregate_bwd'):
             if name in kernel_summary and kernel_summary[name][2] > 0:

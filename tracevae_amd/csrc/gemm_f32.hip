@@ -308,17 +308,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   float *out = split ? (g.slabs + (int64_t)sp * g.M * g.N) : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
   const bool plain = split || (!g.row_scale && !g.accumulate);
-  if (plain && m0 + BM <= g.M && n0 + BN <= g.N) {
-    // interior tile: unchecked stores
+  if (plain && m0 + BM <= g.M) {
+    // all 128 rows of the tile exist: stores are only predicated on the column of the lane
     float *o = out + (m0 + wm * 64 + 4 * kh) * ldo + n0 + wn * 64 + xl;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float bv = (!split && g.bias) ? g.bias[n0 + wn * 64 + j * 32 + xl] : 0.f;
+      const int64_t col = n0 + wn * 64 + j * 32 + xl;
+      if (col < g.N) {
+        const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          o[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32] = acc[i][j][r] + bv;
+          for (int r = 0; r < 16; ++r)
+            o[(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32] = acc[i][j][r] + bv;
+      }
     }
     return;
   }
