@@ -17,6 +17,9 @@
 namespace {
 
 constexpr int MAXH = 4;
+#ifndef TV_GAT_WAVES_PER_SIMD
+#define TV_GAT_WAVES_PER_SIMD 4
+#endif
 constexpr float NEG_SLOPE = 0.2f;  // GATConv negative_slope (appendix A1)
 
 __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
@@ -113,7 +116,7 @@ struct AggArgs {
 };
 
 template <int CH, int HT, bool STATS, bool EPILOGUE>
-__global__ __launch_bounds__(512) void gat_aggregate_fwd_kernel(AggArgs a) {
+__global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
 //   partial sums for dattn_l (del*ft), dattn_r (der*ft), dbias (dout)
 // ------------------------------------------------------------------------------------
 template <int CH, int HT>
-__global__ __launch_bounds__(512) void gat_bwd_node_kernel(AggArgs a) {
+__global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
@@ -491,6 +494,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t nblk, int6
     }                                                                                            \
   } while (0)
 
+int64_t tv_gat_max_blocks() {
+  static int64_t v = 0;
+  if (v == 0) {
+    const char *e = getenv("TV_GAT_BLOCKS");
+    v = (e && atoll(e) > 0) ? atoll(e) : 2048;
+  }
+  return v;
+}
+
 int check_shape(const char *name, int64_t rows_per_rep, int64_t n_rep, int64_t heads,
                 int64_t feats) {
   TV_REQUIRE(rows_per_rep >= 0 && n_rep >= 1, "%s: bad row counts", name);
@@ -557,7 +569,7 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
     TV_GAT_LAUNCH(gat_aggregate_fwd_kernel, grid, block, ldsb, s, a, , true, false);
   } else {
     int64_t blocks = tv_cdiv(rows, TV_STAT_WAVES);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > tv_gat_max_blocks()) blocks = tv_gat_max_blocks();
     const dim3 grid((unsigned)blocks), block(64 * TV_STAT_WAVES);
     if (ep_scale) {
       TV_GAT_LAUNCH(gat_aggregate_fwd_kernel, grid, block, 0, s, a, , false, true);
@@ -613,7 +625,7 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   const bool big = a.c4 > 256;
   {
     int64_t blocks = tv_cdiv(rows, TV_STAT_WAVES);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > tv_gat_max_blocks()) blocks = tv_gat_max_blocks();
     const dim3 grid((unsigned)blocks), block(64 * TV_STAT_WAVES);
     TV_GAT_LAUNCH(gat_bwd_edge_kernel, grid, block, 0, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(edge)");

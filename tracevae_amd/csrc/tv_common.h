@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/tracevae_hip.h"
 
@@ -42,12 +43,20 @@ static inline int64_t tv_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // number of partial slots of the two-stage column reductions (same rule everywhere)
 // (workgroups of TV_STAT_WAVES waves, each wave walks rows with a fixed stride, the waves
 // of a workgroup are combined in wave order, the workgroups in workgroup order)
-#define TV_STAT_MAX_BLOCKS 768
+#define TV_STAT_MAX_BLOCKS 512
 #define TV_STAT_WAVES 8
+static inline int64_t tv_stat_max_blocks(void) {
+  static int64_t v = 0;
+  if (v == 0) {
+    const char *e = getenv("TV_STAT_BLOCKS");   // tuning knob; the default fills the chip once
+    v = (e && atoll(e) > 0) ? atoll(e) : TV_STAT_MAX_BLOCKS;
+  }
+  return v;
+}
 static inline int64_t tv_stat_blocks_host(int64_t rows) {
   int64_t b = tv_cdiv(rows, TV_STAT_WAVES);
   if (b < 1) b = 1;
-  if (b > TV_STAT_MAX_BLOCKS) b = TV_STAT_MAX_BLOCKS;
+  if (b > tv_stat_max_blocks()) b = tv_stat_max_blocks();
   return b;
 }
 
