@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gat_scores_kernel(int64_t rows, int H, in
                                                          float *__restrict__ el,
                                                          float *__restrict__ er) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int f4 = F >> 2;
   for (int64_t r = wave; r < rows; r += nwaves) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * nw;
   const int H = a.H, F = a.F, c4 = a.c4;
   const int64_t HF = (int64_t)H * F;
@@ -145,6 +145,39 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
 #pragma unroll
     for (int h = 0; h < HT; ++h) erv[h] = (h < H) ? a.er[r * H + h] : 0.f;
 
+    float4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (deg <= 64) {
+      // the usual case (a span has few neighbours): one edge per lane, the index and the score
+      // are loaded once and the whole softmax stays in registers
+      const bool live = lane < deg;
+      const int64_t s = live ? base + a.indices[p0 + lane] : 0;
+      float e[HT], al[HT];
+#pragma unroll
+      for (int h = 0; h < HT; ++h)
+        e[h] = (live && h < H) ? tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE) : -INFINITY;
+#pragma unroll
+      for (int h = 0; h < HT; ++h) {
+        const float mx = tv_wave_max(e[h]);
+        const float ex = live ? expf(e[h] - mx) : 0.f;
+        const float den = tv_wave_sum(ex);
+        al[h] = ex / den;
+        if (a.alpha && live && h < H) a.alpha[(rep * a.num_edges + p0 + lane) * H + h] = al[h];
+      }
+      for (int jj = 0; jj < deg; ++jj) {
+        const int64_t sj = __shfl(s, jj, 64);
+        float aj[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) aj[h] = __shfl(al[h], jj, 64);
+        const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * HF);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          if (q < c4) acc[c] = f4_fma(sel_head<HT>(aj, hc[c]), srow[q], acc[c]);
+        }
+      }
+    } else {
     // pass 1: segment max of the edge scores
     float mx[HT];
 #pragma unroll
@@ -177,9 +210,6 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
     for (int h = 0; h < HT; ++h) den[h] = tv_wave_sum(den[h]);
 
     // pass 3: alpha per edge (one edge per lane), then the weighted neighbour sum
-    float4 acc[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c0 = 0; c0 < deg; c0 += 64) {
       const int j = c0 + lane;
       int64_t s = 0;
@@ -208,6 +238,8 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
           if (q < c4) acc[c] = f4_fma(sel_head<HT>(aj, hc[c]), srow[q], acc[c]);
         }
       }
+    }
+
     }
 
     // epilogue: + bias, optional fused BatchNorm(eval)+LeakyReLU or column statistics
@@ -256,7 +288,7 @@ template <int CH, int HT>
 __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * nw;
   const int H = a.H, F = a.F, c4 = a.c4;
   const int64_t HF = (int64_t)H * F;
@@ -374,7 +406,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kerne
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * nw;
   const int H = a.H, F = a.F, c4 = a.c4;
   const int64_t HF = (int64_t)H * F;
