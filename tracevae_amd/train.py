@@ -109,6 +109,29 @@ class FlatParameters(object):
                 p.grad = self.grad[a:b].view(p.shape)
 
 
+    # -- one backward pass without a per-parameter accumulate kernel ----------------------
+    def begin_backward(self) -> None:
+        """Detach the `.grad` views: autograd then hands every parameter its freshly computed
+        gradient tensor instead of launching one `grad += g` kernel per parameter."""
+        for p in self.params.values():
+            p.grad = None
+
+    def collect_grads(self) -> None:
+        """Gather the gradients into the flat bucket with multi-tensor copies (same values as
+        accumulating into a zeroed bucket), then re-attach the views."""
+        self.grad.zero_()
+        dst, src = [], []
+        for n, p in self.params.items():
+            a, b = self.slices[n]
+            view = self.grad[a:b].view(p.shape)
+            if p.grad is not None:
+                dst.append(view)
+                src.append(p.grad)
+            p.grad = view
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+
 class FlatOptimizer(object):
     """RMSprop / Adam over a range of the flat buffer, with clip-by-global-norm
     (`tv_sumsq_partial` -> `tv_sum_partials` -> `tv_optim_step`)."""
@@ -251,9 +274,10 @@ class Trainer(object):
 
     def step(self, G: TraceGraphBatch, eps=None, check_nan: bool = True) -> Dict[str, torch.Tensor]:
         f = self.flat
-        f.zero_grad()
+        f.begin_backward()
         out = self.forward_loss(G, eps)
         out['loss'].backward()
+        f.collect_grads()
         if self.train_cfg.l2_reg:
             # d(l2_reg * sum p^2)/dp = 2 * l2_reg * p on the masked elements
             hip.call('tv_axpy_masked', f.total, 2.0 * self.train_cfg.l2_reg, hip.ptr(f.flat),
