@@ -194,9 +194,10 @@ def main():
     if not np.all(np.isfinite(loss_vals)):
         raise RuntimeError(f'non-finite training loss in the timed region: {loss_vals}')
 
-    # ---- scoring leg (not part of `value`; reported next to it)
+    # ---- scoring leg (not part of `value`; reported next to it): every rank scores its own
+    # shard of traces, no communication; whole-job rate over all ranks
     scoring = None
-    if args.score_k > 0 and rank == 0:
+    if args.score_k > 0:
         vae.eval()
         SB, K = args.score_batch, args.score_k
         def score_one():
@@ -204,17 +205,20 @@ def main():
             return eval_step(vae, TraceGraphBatch.from_store(store, ids, M), K,
                              latency_log_prob_weight=True, clip_nll=100_000.0)[1]
         score_one()
-        torch.cuda.synchronize()
+        barrier()
         ts = time.perf_counter()
         for _ in range(args.score_steps):
             score_one()
-        torch.cuda.synchronize()
+        barrier()
         dt = time.perf_counter() - ts
-        scoring = {'metric': 'nll_scoring_traces_per_sec', 'value': SB * args.score_steps / dt,
-                   'unit': 'traces/s', 'n_z': K, 'batch': SB, 'n_gpus': 1,
-                   'ms_per_step': 1e3 * dt / args.score_steps}
-    if world > 1:
-        dist.barrier()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64,
+                             device=dev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        scoring = {'metric': 'nll_scoring_traces_per_sec',
+                   'value': SB * world * args.score_steps / dt, 'unit': 'traces/s', 'n_z': K,
+                   'batch_per_gpu': SB, 'n_gpus': world, 'ms_per_step': 1e3 * dt / args.score_steps}
 
     if rank == 0:
         value = B * world * args.steps / elapsed
