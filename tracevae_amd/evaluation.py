@@ -14,6 +14,7 @@ from typing import Dict, Iterable, List, Optional
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from .batch import TraceGraphBatch
 from .model import TraceVAE
@@ -138,9 +139,16 @@ class DeviceCollector(object):
             sel = real & (lab == code)[:, None]
             self.chunks.setdefault(self.prefix + name, []).append(values_bm[sel])
 
-    def array(self, key: str) -> np.ndarray:
+    def array(self, key: str, group=None) -> np.ndarray:
+        """All collected values of `key`; with a process group (sharded scoring) the shards of
+        every rank, concatenated in rank order."""
         parts = self.chunks.get(key, [])
-        return torch.cat(parts).cpu().numpy() if parts else np.zeros([0], np.float32)
+        local = torch.cat(parts).cpu().numpy() if parts else np.zeros([0], np.float32)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            shards = [None] * dist.get_world_size(group)
+            dist.all_gather_object(shards, local, group=group)
+            local = np.concatenate(shards)
+        return local
 
 
 def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: int,
@@ -152,7 +160,7 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
                     operation_id_dict_out: Optional[DeviceCollector] = None,
                     latency_std_dict_out: Optional[DeviceCollector] = None,
                     latency_reldiff_dict_out: Optional[DeviceCollector] = None,
-                    **_ignored) -> Dict[str, float]:
+                    process_group=None, **_ignored) -> Dict[str, float]:
     """The scoring driver (evaluation.py:40-283): score every batch of the stream, keep scores
     and collected per-node values on the GPU until the end (one device->host copy each), then
     the summary of `analyze_anomaly_nll` and the optional `.npz` (`nll_list`, `label_list`,
@@ -200,15 +208,31 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
                     latency_reldiff_dict_out.add(rel.abs(), count, step_labels)
     finally:
         vae.train(was_training)
-    nll_list = torch.cat(nll_chunks).cpu().numpy() if nll_chunks else np.zeros([0], np.float32)
+    nll_parts = [c.cpu().numpy() for c in nll_chunks]
+    loss_parts = torch.cat(loss_chunks).cpu().numpy().tolist() if loss_chunks else []
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        # sharded scoring (rank r scored batches r, r+W, ... of the stream, no communication
+        # until here): put the batches of all ranks back into stream order
+        world = dist.get_world_size(process_group)
+        shards = [None] * world
+        dist.all_gather_object(shards, (nll_parts, label_chunks, loss_parts, weights),
+                               group=process_group)
+        nll_parts, label_chunks, loss_parts, weights = [], [], [], []
+        for i in range(max(len(sh[0]) for sh in shards)):
+            for sh in shards:
+                if i < len(sh[0]):
+                    nll_parts.append(sh[0][i]); label_chunks.append(sh[1][i])
+                    loss_parts.append(sh[2][i]); weights.append(sh[3][i])
+    nll_list = np.concatenate(nll_parts) if nll_parts else np.zeros([0], np.float32)
     label_list = np.concatenate(label_chunks) if label_chunks else np.zeros([0], np.int64)
     result: Dict[str, float] = {}
-    if loss_chunks:
+    if loss_parts:
         # batch-size weighted mean of the per-batch mean losses (evaluation.py:247-260)
         w = np.asarray(weights, dtype=np.float64)
-        result['test_loss'] = float(np.sum(torch.cat(loss_chunks).cpu().numpy() * (w / w.sum())))
+        result['test_loss'] = float(np.sum(np.asarray(loss_parts) * (w / w.sum())))
     result.update(analyze_anomaly_nll(nll_list, label_list, threshold=test_threshold))
-    if nll_output_file is not None:
+    is_writer = not (dist.is_available() and dist.is_initialized()) or dist.get_rank(process_group) == 0
+    if nll_output_file is not None and is_writer:
         os.makedirs(os.path.dirname(os.path.abspath(nll_output_file)), exist_ok=True)
         np.savez_compressed(nll_output_file, nll_list=nll_list, label_list=label_list,
                             anomaly_degree=nll_list / result['best_threshold_latency'])

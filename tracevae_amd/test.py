@@ -87,7 +87,7 @@ def evaluate_nll(vae: TraceVAE, test_stream: Iterable[TraceGraphBatch],
                  threshold_amplify: float = 1.0, no_latency_log_prob_weight: bool = False,
                  use_std_limit: bool = False, std_limit_global: bool = False,
                  std_limit_fixed: Optional[float] = None, std_limit_p: float = 0.99,
-                 std_limit_amplify: float = 1.0, rng=None) -> Dict[str, float]:
+                 std_limit_amplify: float = 1.0, rng=None, process_group=None) -> Dict[str, float]:
     """`evaluate_nll` of test.py with its option names (the `infer_*` flags carry a trailing
     underscore here because the functions above own the plain names).  Returns the merged
     result dict: `train_*` / `val_*` / `test_*` metrics, `bias_std`, `train_threshold`,
@@ -112,7 +112,7 @@ def evaluate_nll(vae: TraceVAE, test_stream: Iterable[TraceGraphBatch],
             latency_log_prob_weight=not no_latency_log_prob_weight, std_limit=std_limit,
             test_threshold=threshold, clip_nll=clip_nll, nll_output_file=out_file,
             operation_id_dict_out=operation_id, latency_std_dict_out=latency_std,
-            latency_reldiff_dict_out=latency_reldiff)
+            latency_reldiff_dict_out=latency_reldiff, process_group=process_group)
         nll_result[category] = r.pop('_nll_list')
         r.pop('_label_list')
         results.update({f'{category}_{key}': v for key, v in r.items()})
@@ -123,7 +123,8 @@ def evaluate_nll(vae: TraceVAE, test_stream: Iterable[TraceGraphBatch],
         run(train_stream, 'train', 1)
         run(val_stream, 'val', 1)
         if infer_bias_std_:
-            bias_std = infer_bias_std(latency_reldiff.array('val_normal'), bias_std_normal_p)
+            bias_std = infer_bias_std(latency_reldiff.array('val_normal', process_group),
+                                      bias_std_normal_p)
             results['bias_std'] = bias_std
             vae.config.latency.decoder.biased_normal_std_threshold = bias_std
         if infer_threshold_:
@@ -133,7 +134,8 @@ def evaluate_nll(vae: TraceVAE, test_stream: Iterable[TraceGraphBatch],
             results.update(thresholds)
         if use_std_limit:
             std_group_limit = infer_std_limit(
-                operation_id.array('val_normal'), latency_std.array('val_normal'), num_operations,
+                operation_id.array('val_normal', process_group),
+                latency_std.array('val_normal', process_group), num_operations,
                 std_limit_p, std_limit_amplify, std_limit_global, std_limit_fixed)
     run(test_stream, 'test', n_z, thresholds.get('val_threshold'), std_group_limit, nll_out)
     results['std_limit'] = std_group_limit
@@ -143,6 +145,7 @@ def evaluate_nll(vae: TraceVAE, test_stream: Iterable[TraceGraphBatch],
 def main(argv=None) -> int:
     """`python -m tracevae_amd.test evaluate-nll -M <model dir|.pt> -D <dataset> [flags]`: the
     options of test.sh / test.py:58-84 (plot outputs are not produced)."""
+    import os
     import torch
     from .batch import DeviceTraceStore
     from .data_process import TEST_SETS, concat_flat, load_dataset
@@ -172,9 +175,13 @@ def main(argv=None) -> int:
         from . import hip
         raise hip.HipLibraryError('the accelerated path needs a GPU (there is no CPU fallback); '
                                   f'--device={args.device} cannot be honoured')
+    import torch.distributed as dist
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world > 1:      # sharded scoring: rank r takes batches r, r+W, ...
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
+        dist.init_process_group(os.environ.get('TRACEVAE_DIST_BACKEND', 'nccl'))
     device = torch.device('cuda', torch.cuda.current_device())
     # the data set root comes from the train config unless -D is given (test.py:108-109)
-    import os
     cfg_dir = os.path.dirname(os.path.dirname(os.path.abspath(args.model_path))) \
         if args.model_path.endswith('.pt') else args.model_path
     data_dir = args.data_dir
@@ -185,7 +192,8 @@ def main(argv=None) -> int:
     v = id_manager.num_operations
     vae, _config = load_model(args.model_path, v, extra_args=extra, device=device)
     store = lambda flat: DeviceTraceStore(flat, latency_range, v)
-    stream = lambda flat, shuffle: StoreStream(store(flat), args.batch_size, shuffle=shuffle)
+    stream = lambda flat, shuffle: StoreStream(store(flat), args.batch_size, shuffle=shuffle,
+                                               rank=rank, world_size=world)
     need_tv = args.use_train_val or args.infer_bias_std or args.infer_threshold or args.use_std_limit
     result = evaluate_nll(
         vae, stream(concat_flat(sets[n] for n in TEST_SETS), False),
@@ -199,11 +207,15 @@ def main(argv=None) -> int:
         no_latency_log_prob_weight=args.no_latency_log_prob_weight,
         use_std_limit=args.use_std_limit, std_limit_global=args.std_limit_global,
         std_limit_fixed=args.std_limit_fixed, std_limit_p=args.std_limit_p,
-        std_limit_amplify=args.std_limit_amplify)
+        std_limit_amplify=args.std_limit_amplify,
+        rng=np.random.RandomState(0) if world > 1 else None)   # same bootstrap on every rank
     limit = result.pop('std_limit')
     if limit is not None:
         result['std_limit_max'] = float(limit.max())
-    print(json.dumps(result, indent=1))
+    if rank == 0:
+        print(json.dumps(result, indent=1))
+    if world > 1:
+        dist.destroy_process_group()
     return 0
 
 
