@@ -231,6 +231,12 @@ class Trainer(object):
         part = [n for n in f.all_names if n.startswith('latency_vae.')] if latency_only \
             else list(f.all_names)
         self.part_names = part
+        # parameters outside the phase are frozen: autograd then skips every backward kernel that
+        # only feeds them (in phase 2 the whole struct-VAE backward), with the same update as
+        # the reference, whose optimizer simply ignores those gradients (train.py:476-487)
+        in_part = set(part)
+        for n, p in f.params.items():
+            p.requires_grad_(n in in_part)
         start = f.tail_start if latency_only else 0
         self.optimizer = FlatOptimizer(f, self.train_cfg.optimizer, start, f.total)
         self.optimizer.set_lr(learning_rate_for_epoch(self.train_cfg, self.epoch - 1))
