@@ -302,3 +302,26 @@ def test_evaluate_nll_flow_thresholds_and_std_limit(device, tmp_path):
     op = int(G.build_dgl().node_type[0])
     sel = G.build_dgl().node_type.cpu().numpy() == op
     assert lim[op] == np.float32(1.5 * float(np.percentile(want_std[sel], 99.0)))
+
+
+def test_learning_rate_schedule_follows_the_finished_epoch_count(device):
+    """train.py:374-383: the rate is set when an epoch ENDS, from the number of finished epochs,
+    so epoch e runs at initial_lr * ratio ** ((e - 1) // anneal_epochs); phase 2 starts a new
+    optimizer at the rate of its first epoch."""
+    from tracevae_amd.train import Trainer
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, 40, 16, 16, 2, 6, seed=21)
+    cfg.train.initial_lr, cfg.train.lr_anneal_ratio, cfg.train.lr_anneal_epochs = 1e-3, 0.1, 30
+    trainer = Trainer(vae, cfg, world_size=1)
+    rates = {}
+    for epoch in (1, 29, 30, 31, 60, 61):
+        trainer.set_epoch(epoch)
+        rates[epoch] = trainer.optimizer.lr
+    assert rates[1] == rates[29] == rates[30] == pytest.approx(1e-3)
+    assert rates[31] == rates[60] == pytest.approx(1e-4)
+    assert rates[61] == pytest.approx(1e-5)
+    trainer.epoch = 41
+    trainer.set_phase(latency_only=True)
+    assert trainer.optimizer.lr == pytest.approx(1e-4)
+    assert all(p.requires_grad == n.startswith('latency_vae.') for n, p in vae.named_parameters())
+    trainer.set_phase(latency_only=False)
+    assert all(p.requires_grad for p in vae.parameters())
