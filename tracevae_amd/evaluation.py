@@ -77,7 +77,9 @@ def analyze_anomaly_nll(nll_list: np.ndarray, label_list: np.ndarray,
 
     def guarded(fn, default, *args):
         try:
-            return fn(*args)
+            with warnings.catch_warnings():      # sklearn warns about absent classes
+                warnings.simplefilter('ignore')
+                return fn(*args)
         except Exception:
             return default
 
