@@ -40,7 +40,10 @@ def _setup(device, V, M, width, layers, batch, seed=0, extra=(), anomaly_ratio=0
     return cfg, vae, store, flat, lr, P, buf, names
 
 
-@pytest.mark.parametrize('V,M,width,layers,batch', [(60, 16, 16, 2, 9), (300, 32, 500, 4, 16)])
+@pytest.mark.parametrize('V,M,width,layers,batch', [(60, 16, 16, 2, 9), (300, 32, 500, 4, 16),
+                                                   # BASELINE configs[1] dims: 1k operations, M = 100,
+                                                   # 4 x (2 x 500) GAT stacks
+                                                   (1001, 100, None, None, 24)])
 def test_train_step_loss_and_gradients(device, V, M, width, layers, batch):
     from oracle.model import OracleTraceVAE
     from tracevae_amd.batch import TraceGraphBatch
@@ -101,15 +104,19 @@ def test_train_step_loss_and_gradients(device, V, M, width, layers, batch):
             assert rel_err(sd[k], v) < PATH_TOL, k
 
 
-@pytest.mark.parametrize('use_flow', [True, False])
-def test_eval_step_scores(device, use_flow):
+@pytest.mark.parametrize('use_flow,dims', [(True, (80, 20, 24, 2, 11, 5)), (False, (80, 20, 24, 2, 11, 5)),
+                                           # BASELINE configs[1] / [3] dims
+                                           (True, (1001, 100, None, None, 12, 3))])
+def test_eval_step_scores(device, use_flow, dims):
     from oracle.model import OracleTraceVAE
     from tracevae_amd.batch import TraceGraphBatch
     from tracevae_amd.evaluation import eval_step
-    V, M, K = 80, 20, 5
+    V, M, width, layers, nb, K = dims
+    # an untrained full-size model scores far above the reference's default clip of 1e5
+    clip = 100_000.0 if V < 1000 else 1e9
     extra = () if use_flow else ('--model.struct.decoder.use_prior_flow=false',)
-    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 24, 2, 11, seed=3, extra=extra,
-                                                       anomaly_ratio=0.3)
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, width, layers, nb, seed=3,
+                                                       extra=extra, anomaly_ratio=0.3)
     vae.eval()
     B = len(flat)
     g = torch.Generator().manual_seed(2)
@@ -119,11 +126,11 @@ def test_eval_step_scores(device, use_flow):
     ob = oracle_batch(flat, lr, V, M)
     ref = orc.eval_step(P, buf, ob, eps_z.double(), eps_z2.double(), use_biased=True,
                         use_latency_biased=True, latency_log_prob_weight=True,
-                        std_limit=std_limit.double(), clip_nll=100_000.0)
+                        std_limit=std_limit.double(), clip_nll=clip)
     G = TraceGraphBatch.from_store(store, np.arange(B), M)
     loss, nll, chain = eval_step(vae, G, K, use_biased=True, use_latency_biased=True,
                                  latency_log_prob_weight=True, std_limit=std_limit.to(device),
-                                 clip_nll=100_000.0, eps={'z': eps_z, 'z2': eps_z2},
+                                 clip_nll=clip, eps={'z': eps_z, 'z2': eps_z2},
                                  return_chain=True)
     assert vae.latency_vae.last_compact
     assert rel_err(nll, ref['nll']) < PATH_TOL
@@ -139,7 +146,7 @@ def test_eval_step_scores(device, use_flow):
     e1 = {'z': eps_z[:, :half], 'z2': eps_z2[:, :half]}
     e2 = {'z': eps_z[:, half:], 'z2': eps_z2[:, half:]}
     kw = dict(use_biased=True, use_latency_biased=True, latency_log_prob_weight=True,
-              std_limit=std_limit.to(device), clip_nll=100_000.0)
+              std_limit=std_limit.to(device), clip_nll=clip)
     _, n1 = eval_step(vae, TraceGraphBatch.from_store(store, np.arange(half), M), K, eps=e1, **kw)
     _, n2 = eval_step(vae, TraceGraphBatch.from_store(store, np.arange(half, B), M), K, eps=e2, **kw)
     assert rel_err(torch.cat([n1, n2]), nll) < 1e-5
