@@ -38,7 +38,8 @@ def measured_traffic(args):
     """PMC counters cannot be read from inside the timed run; the figure comes from the
     committed rocprofv3 --pmc passes over this same command, and only for the workload they
     were collected on."""
-    if (args.batch_size, args.max_node_count, args.num_operations) != (512, 100, 1001):
+    if (args.batch_size, args.max_node_count, args.num_operations, args.gnn_width, args.z_dim) != \
+            (512, 100, 1001, None, 10):
         return None
     try:
         with open(TRAFFIC_PROFILE) as f:
@@ -61,17 +62,23 @@ def parse_args():
     ap.add_argument('--score-steps', type=int, default=3)
     ap.add_argument('--cpu-baseline-traces', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gnn-width', type=int, default=None, help='per-head GAT width (default 500)')
+    ap.add_argument('--z-dim', type=int, default=10, help='z / z2 dimension (train.sh: 10)')
     ap.add_argument('--gemm-shapes', action='store_true', help='per-shape GEMM table on stderr')
     ap.add_argument('--seed', type=int, default=1234)
     return ap.parse_args()
 
 
-def make_config():
+def make_config(width=None, z_dim=10):
     from tracevae_amd.config import ExpConfig, parse_flags
     cfg = ExpConfig()
-    parse_flags(cfg, ['--model.struct.z_dim=10', '--model.struct.decoder.use_prior_flow=true',
-                      '--train.z_unit_ball_reg=1', '--model.latency.z2_dim=10',
+    parse_flags(cfg, [f'--model.struct.z_dim={z_dim}', '--model.struct.decoder.use_prior_flow=true',
+                      '--train.z_unit_ball_reg=1', f'--model.latency.z2_dim={z_dim}',
                       '--model.latency.decoder.condition_on_z=true'])
+    if width is not None:     # configs[4]: doubled GNN width
+        mc = cfg.model
+        for sec in (mc.struct.encoder, mc.struct.decoder, mc.latency.encoder, mc.latency.decoder):
+            sec.gnn_layers = [width] * len(sec.gnn_layers)
     return cfg
 
 
@@ -146,7 +153,7 @@ def main():
     from tracevae_amd.train import Trainer
 
     V, M, B = args.num_operations, args.max_node_count, args.batch_size
-    cfg = make_config()
+    cfg = make_config(args.gnn_width, args.z_dim)
     spec = SyntheticSpec(num_operations=V, max_spans=M, seed=args.seed)
     # every rank generates its own shard of the synthetic set (seeded by rank)
     flat, lr = generate_flat(spec, args.pool, seed=args.seed + 1 + rank)
