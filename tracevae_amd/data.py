@@ -24,22 +24,44 @@ import numpy as np
 import yaml
 
 __all__ = [
-    'TraceGraphNodeFeatures', 'TraceGraphNode', 'TraceGraphVectors', 'TraceGraph',
+    'TraceGraphNodeFeatures', 'TraceGraphNodeReconsScores', 'TraceGraphSpan', 'TraceGraphNode', 'TraceGraphVectors', 'TraceGraph',
     'IDAssign', 'TraceGraphIDManager', 'TraceGraphLatencyRangeFile',
     'FlatTraces', 'flatten_trace_graphs', 'load_trace_csv', 'df_to_trace_graphs',
 ]
 
 
+class _SlotState(object):
+    """Pickle state in the form the reference's `__slots__` classes produce and accept
+    (`(None, {field: value})`), so `bytes_db` files go both ways."""
+
+    def __getstate__(self):
+        return None, dict(vars(self))
+
+
 @dataclass
-class TraceGraphNodeFeatures(object):
+class TraceGraphNodeFeatures(_SlotState):
     span_count: int
     avg_latency: float
     max_latency: float
     min_latency: float
 
 
+@dataclass
+class TraceGraphNodeReconsScores(object):
+    edge_logit: float
+    operation_logit: float
+    avg_latency_nstd: float
+
+
+@dataclass
+class TraceGraphSpan(_SlotState):
+    span_id: Optional[int]
+    start_time: Optional[Any]
+    latency: float
+
+
 @dataclass(eq=False)
-class TraceGraphNode(object):
+class TraceGraphNode(_SlotState):
     node_id: Optional[int]
     service_id: Optional[int]
     operation_id: int
@@ -67,7 +89,7 @@ class TraceGraphNode(object):
 
 
 @dataclass
-class TraceGraphVectors(object):
+class TraceGraphVectors(_SlotState):
     u: np.ndarray            # int64 [n-1] parent ids   (u[e] < v[e])
     v: np.ndarray            # int64 [n-1] child ids
     node_type: np.ndarray    # int64 [n]
@@ -80,7 +102,7 @@ class TraceGraphVectors(object):
 
 
 @dataclass
-class TraceGraph(object):
+class TraceGraph(_SlotState):
     version: int
     trace_id: Optional[Tuple[int, int]]
     parent_id: Optional[int]

@@ -7,6 +7,10 @@ set of the accelerated path as its output instead of sqlite + snappy + pickled `
 Each file holds one `FlatTraces` (concatenated per-trace arrays), i.e. what
 `tv_batch_build` consumes, so training never unpickles a graph.  `load_dataset()` reads them
 back (and falls back to the CSV files when a set was not preprocessed).
+
+`python -m tracevae_amd.data_process convert-db -i <dataset>` does the same for sets the
+reference has already processed (`<dataset>/processed/<name>/_bytes.db`, read by `bytes_db`);
+`load_dataset()` also reads those directly when no `.npz` exists.
 """
 import argparse
 import os
@@ -18,7 +22,8 @@ import numpy as np
 from .data import (FlatTraces, TraceGraphIDManager, TraceGraphLatencyRangeFile,
                    df_to_trace_graphs, flatten_trace_graphs, load_trace_csv)
 
-__all__ = ['csv_to_flat', 'save_flat', 'load_flat', 'preprocess', 'load_dataset', 'concat_flat']
+__all__ = ['csv_to_flat', 'db_to_flat', 'save_flat', 'load_flat', 'preprocess', 'convert_db',
+           'load_dataset', 'concat_flat']
 
 _FIELDS = ('node_offsets', 'u', 'v', 'node_type', 'avg_latency', 'max_latency', 'min_latency',
            'labels')
@@ -70,6 +75,33 @@ def csv_to_flat(input_dir: str, name: str, id_manager: TraceGraphIDManager) -> D
     return out
 
 
+def db_to_flat(db_dir: str, chunk: int = 8192) -> FlatTraces:
+    """`<dataset>/processed/<name>/` (a reference `_bytes.db`) -> flat arrays, streaming: at
+    most `chunk` graph objects are alive at a time."""
+    from .bytes_db import BytesSqliteDB, TraceGraphDB
+    parts, pending = [], []
+    with TraceGraphDB(BytesSqliteDB(db_dir)) as db:
+        for g in db:
+            pending.append(g)
+            if len(pending) >= chunk:
+                parts.append(flatten_trace_graphs(pending))
+                pending = []
+    if pending or not parts:
+        parts.append(flatten_trace_graphs(pending))
+    return parts[0] if len(parts) == 1 else concat_flat(parts)
+
+
+def convert_db(input_dir: str, output_dir: Optional[str] = None) -> None:
+    output_dir = output_dir or input_dir
+    processed = os.path.join(input_dir, 'processed')
+    for name in sorted(os.listdir(processed)):
+        if os.path.isfile(os.path.join(processed, name, '_bytes.db')):
+            flat = db_to_flat(os.path.join(processed, name))
+            dst = os.path.join(output_dir, 'processed', f'{name}.npz')
+            save_flat(dst, flat)
+            print(f'{name}: {len(flat)} traces, {int(flat.node_offsets[-1])} nodes -> {dst}')
+
+
 def preprocess(input_dir: str, output_dir: str) -> None:
     id_manager = TraceGraphIDManager(os.path.join(input_dir, 'id_manager'))
     for name in ('train', 'val', 'test'):
@@ -81,8 +113,8 @@ def preprocess(input_dir: str, output_dir: str) -> None:
 
 def load_dataset(root_dir: str, names=('train', 'val') + TEST_SETS
                  ) -> Tuple[Dict[str, FlatTraces], TraceGraphIDManager, TraceGraphLatencyRangeFile]:
-    """`<root>/id_manager` + the data sets, from `<root>/processed/*.npz` when present, else
-    straight from `<root>/*.csv`."""
+    """`<root>/id_manager` + the data sets, from `<root>/processed/<name>.npz` when present, else
+    from the reference's `<root>/processed/<name>/_bytes.db`, else straight from `<root>/*.csv`."""
     id_manager = TraceGraphIDManager(os.path.join(root_dir, 'id_manager'))
     latency_range = TraceGraphLatencyRangeFile(os.path.join(root_dir, 'id_manager'),
                                                require_exists=True)
@@ -92,6 +124,10 @@ def load_dataset(root_dir: str, names=('train', 'val') + TEST_SETS
         path = os.path.join(root_dir, 'processed', f'{name}.npz')
         if os.path.exists(path):
             sets[name] = load_flat(path)
+            continue
+        db_dir = os.path.join(root_dir, 'processed', name)
+        if os.path.isfile(os.path.join(db_dir, '_bytes.db')):
+            sets[name] = db_to_flat(db_dir)
             continue
         csv_name = 'test' if name in TEST_SETS else name
         if csv_name not in csv_cache:
@@ -106,7 +142,14 @@ def main(argv=None) -> int:
     p = sub.add_parser('preprocess')
     p.add_argument('-i', '--input-dir', required=True)
     p.add_argument('-o', '--output-dir', '--output_dir', dest='output_dir', required=True)
+    p = sub.add_parser('convert-db')
+    p.add_argument('-i', '--input-dir', required=True)
+    p.add_argument('-o', '--output-dir', '--output_dir', dest='output_dir', default=None)
     args = ap.parse_args(argv)
+    if args.command == 'convert-db':
+        convert_db(os.path.abspath(args.input_dir),
+                   os.path.abspath(args.output_dir) if args.output_dir else None)
+        return 0
     preprocess(os.path.abspath(args.input_dir), os.path.abspath(args.output_dir))
     return 0
 
