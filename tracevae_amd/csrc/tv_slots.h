@@ -6,8 +6,8 @@
 #pragma once
 #include "tv_common.h"
 
-#define TV_SLOT_COLS 16
-#define TV_SLOT_GROUPS 16
+#define TV_SLOT_COLS 8
+#define TV_SLOT_GROUPS 32
 
 static inline unsigned tv_slot_grid(int64_t n) { return (unsigned)tv_cdiv(n, TV_SLOT_COLS); }
 
@@ -24,7 +24,22 @@ __device__ __forceinline__ void tv_slot_sums(const float *__restrict__ partial, 
 #pragma unroll
   for (int p = 0; p < NS; ++p) acc[p] = 0.0;
   if (valid) {
-    for (int64_t b = grp; b < nblk; b += TV_SLOT_GROUPS) {
+    // 4 slots per trip so the loads of a trip are in flight together; the additions stay in
+    // slot order
+    int64_t b = grp;
+    for (; b + 3 * TV_SLOT_GROUPS < nblk; b += 4 * TV_SLOT_GROUPS) {
+      float v[4][NS];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+          v[j][p] = partial[(b + j * TV_SLOT_GROUPS) * slot_stride + p * plane_stride + idx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) acc[p] += (double)v[j][p];
+    }
+    for (; b < nblk; b += TV_SLOT_GROUPS) {
 #pragma unroll
       for (int p = 0; p < NS; ++p) acc[p] += (double)partial[b * slot_stride + p * plane_stride + idx];
     }
