@@ -33,6 +33,10 @@ extern "C" {
 #define TV_ERR_LAUNCH (-2)  /* HIP reported a launch error */
 #define TV_ERR_WORKSPACE (-3) /* workspace too small */
 
+/* limits of tv_realnvp_logprob_* */
+#define TV_FLOW_MAX_LEVELS 8
+#define TV_FLOW_MAX_DIM 20
+
 /* status bits written by tv_batch_build into *status (device int32) */
 #define TV_BATCH_TOO_MANY_NODES 1 /* a trace has more than max_node_count nodes           */
 #define TV_BATCH_BAD_EDGE 2       /* an edge violates 0 <= u < v < n                        */
@@ -305,6 +309,30 @@ int tv_normal_ll_fwd(int64_t rows, int64_t dim, const float *x, const float *mea
 int tv_normal_ll_bwd(int64_t rows, int64_t dim, const float *x, const float *mean,
                      const float *logstd_raw, float lo, float hi, const float *dll, float *dx,
                      float *dmean, float *dlogstd_raw, void *stream);
+
+/* log p(z) of the RealNVP prior of the struct VAE: `levels` x (ActNorm, affine coupling with ONE
+ * hidden layer and sigmoid scale, invertible dense), then the unit normal
+ * (model/realnvp_flow.py:18-49 via make_realnvp_flow(...).invert(), struct_vae.py:148-149,
+ * 251-254; tensorkit ActNorm / CouplingLayer / InvertibleDense).  z [rows, dim] -> log_prob [rows].
+ * `params` / `grads`: HOST arrays of levels*9 device pointers, per level in this order:
+ *   0 act-norm bias [dim]         1 act-norm pre_scale [dim]
+ *   2 hidden weight [hidden, n1]  3 hidden bias [hidden]          (n1 = dim/2, n2 = dim - n1)
+ *   4 shift weight [n2, hidden]   5 shift bias [n2]
+ *   6 pre-scale weight [n2, hidden]   7 pre-scale bias [n2]
+ *   8 dense kernel [dim, dim]  (y = x K^T; log|det K| and K^-T are computed on the device)
+ * A level maps x -> K [x1, (x2 + shift(x1)) * sigmoid(pre(x1) + 2)] with x = (x_in + bias) *
+ * exp(pre_scale); LeakyReLU(slope) after the hidden layer.
+ * ws: tv_realnvp_workspace_floats(rows, ...) floats; the backward call must get the workspace
+ * its forward call filled (same parameters).  A NULL entry of `grads` skips that tensor.
+ * tv_realnvp_supported: kernels exist for dim 10 / 16 / 20 with hidden 64. */
+int tv_realnvp_supported(int dim, int hidden);
+int64_t tv_realnvp_workspace_floats(int64_t rows, int levels, int dim, int hidden);
+int tv_realnvp_logprob_fwd(int64_t rows, int levels, int dim, int hidden, float slope,
+                           const float *z, const float *const *params, float *ws,
+                           float *log_prob, void *stream);
+int tv_realnvp_logprob_bwd(int64_t rows, int levels, int dim, int hidden, float slope,
+                           const float *z, const float *const *params, const float *dlog_prob,
+                           float *ws, float *dz, float *const *grads, void *stream);
 
 /* p(latency|z2,G) (model/latency_vae.py:346-444, distributions.py:105-113, 267-286, 300-315,
  * 341-356): feats [K*B*M, 2] = (mean, raw logstd); logstd = max(raw, logstd_min), then

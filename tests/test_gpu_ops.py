@@ -556,3 +556,87 @@ def test_flat_optimizer(device, kind):
         ropt.step()
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert rel_err(p, q) < 1e-4, n
+
+
+# ---------------------------------------------------------------------------------------
+# RealNVP prior: the fused kernels against the PyTorch formulation of the same flow in float64
+# (itself checked against the oracle by the model-level tests); tolerance 1e-4 relative
+# ---------------------------------------------------------------------------------------
+def _random_flow(dim, levels, seed, device):
+    from tracevae_amd.config import RealNVPFlowConfig
+    from tracevae_amd.model import InverseRealNVP
+    torch.manual_seed(seed)
+    cfg = RealNVPFlowConfig()
+    cfg.flow_levels = levels
+    flow = InverseRealNVP(dim, cfg)
+    with torch.no_grad():
+        for name, p in flow.named_parameters():
+            if name.endswith('.kernel'):
+                p.add_(0.2 * torch.randn_like(p))                # not orthogonal any more
+            elif 'shared' in name:
+                p.add_(0.05 * torch.randn_like(p))
+            else:                                                # zero-initialised tensors
+                p.copy_(0.3 * torch.randn_like(p))
+    for m in flow.modules():
+        if hasattr(m, 'initialized'):
+            m.initialized = True
+    return flow.to(device)
+
+
+@pytest.mark.parametrize('dim,levels,rows', [(10, 5, 512), (10, 5, 1), (10, 1, 63), (10, 5, 65),
+                                             (10, 8, 1300), (16, 3, 200), (20, 5, 130)])
+def test_realnvp_log_prob(device, dim, levels, rows):
+    flow = _random_flow(dim, levels, 100 + rows, device)
+    ref = _random_flow(dim, levels, 100 + rows, device).double()
+    assert flow._fused_params(dim) is not None
+    gen = torch.Generator(device='cpu').manual_seed(rows)
+    z = (1.5 * torch.randn(rows, dim, generator=gen)).to(device)
+    w = torch.randn(rows, generator=gen).to(device)
+    zf = z.clone().requires_grad_(True)
+    lp = flow.log_prob(zf)
+    (lp * w).sum().backward()
+    zr = z.double().requires_grad_(True)
+    lp_ref = ref.log_prob_torch(zr)
+    (lp_ref * w.double()).sum().backward()
+    assert rel_err(lp, lp_ref) < 1e-4
+    assert rel_err(zf.grad, zr.grad) < 1e-4
+    for (name, p), (_, q) in zip(flow.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, name
+        assert rel_err(p.grad, q.grad) < 1e-4, name
+
+
+def test_realnvp_k_samples_frozen_parameters_and_fallback(device):
+    flow = _random_flow(10, 5, 7, device)
+    ref = _random_flow(10, 5, 7, device).double()
+    z = torch.randn(3, 40, 10, device=device)
+    assert rel_err(flow.log_prob(z), ref.log_prob_torch(z.double())) < 1e-4   # [K, B] leading dims
+    assert flow.log_prob(z).shape == (3, 40)
+    # frozen parameters (phase 2 of training): only dz comes back
+    for p in flow.parameters():
+        p.requires_grad_(False)
+    zf = z.clone().requires_grad_(True)
+    flow.log_prob(zf).sum().backward()
+    zr = z.double().requires_grad_(True)
+    ref.log_prob_torch(zr).sum().backward()
+    assert rel_err(zf.grad, zr.grad) < 1e-4
+    assert all(p.grad is None for p in flow.parameters())
+    # empty input
+    assert flow.log_prob(torch.zeros(0, 10, device=device)).shape == (0,)
+    # a flow the kernel does not cover keeps the PyTorch formulation
+    from tracevae_amd.config import RealNVPFlowConfig
+    from tracevae_amd.model import InverseRealNVP
+    cfg = RealNVPFlowConfig()
+    cfg.coupling_hidden_layer_units = 32
+    other = InverseRealNVP(10, cfg).to(device)
+    for m in other.modules():
+        if hasattr(m, 'initialized'):
+            m.initialized = True
+    assert other._fused_params(10) is None
+    assert other.log_prob(z).shape == (3, 40)
+    # bad shapes are refused on the host
+    from tracevae_amd import ops
+    params, levels, hidden = flow._fused_params(10)
+    with pytest.raises(ValueError):
+        ops.realnvp_log_prob(z, params[:-1], levels, hidden, 0.01)
+    with pytest.raises(ValueError):
+        ops.realnvp_log_prob(torch.randn(4, 10, device=device), [params[1]] + params[1:], 5, 32, 0.01)

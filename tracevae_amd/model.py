@@ -41,6 +41,8 @@ BN_EPSILON = 1e-6
 # reference's padded [B*M] rows (A/B switch for tests and measurements)
 COMPACT_LATENCY_DECODER = os.environ.get('TRACEVAE_COMPACT_LATDEC', '1') != '0'
 LRELU_SLOPE = 0.01
+# the RealNVP prior as one HIP kernel per direction (0: the PyTorch formulation, for A/B runs)
+FUSED_PRIOR_FLOW = os.environ.get('TRACEVAE_FUSED_FLOW', '1') != '0'
 
 
 # ---------------------------------------------------------------------------------------
@@ -394,7 +396,43 @@ class InverseRealNVP(nn.Module):
             flows += [ActNorm(dim), CouplingLayer(dim, cfg), InvertibleDense(dim)]
         self.original_flow = _SequentialFlow(flows)
 
+    def _fused_params(self, dim: int):
+        """The 9 tensors per level `tv_realnvp_logprob_fwd` takes, or None when this flow is not
+        the shape the kernel covers (then, and for the data-dependent ActNorm initialisation
+        of the first batch, the PyTorch formulation below runs)."""
+        flows = list(self.original_flow.flows)
+        levels = len(flows) // 3
+        if not FUSED_PRIOR_FLOW or levels == 0:
+            return None
+        params = []
+        hidden = None
+        for lvl in range(levels):
+            an, cp, dense = flows[3 * lvl:3 * lvl + 3]
+            br = cp.shift_and_pre_scale
+            if not an.initialized or cp.scale_type != 'sigmoid' or len(br.shared) != 1:
+                return None
+            h = br.shared[0].weight_store.value.shape[0]
+            if hidden is None:
+                hidden = h
+            if h != hidden:
+                return None
+            params += [an.bias, an.pre_scale, br.shared[0].weight_store.value,
+                       br.shared[0].bias_store.value,
+                       br.branches[0][0].weight_store.value, br.branches[0][0].bias_store.value,
+                       br.branches[1][0].weight_store.value, br.branches[1][0].bias_store.value,
+                       dense.kernel]
+        if not ops.realnvp_supported(dim, hidden, levels):
+            return None
+        return params, levels, hidden
+
     def log_prob(self, z: torch.Tensor) -> torch.Tensor:
+        fused = self._fused_params(z.shape[-1]) if z.is_cuda else None
+        if fused is not None:
+            params, levels, hidden = fused
+            return ops.realnvp_log_prob(z, params, levels, hidden, LRELU_SLOPE)
+        return self.log_prob_torch(z)
+
+    def log_prob_torch(self, z: torch.Tensor) -> torch.Tensor:
         lead = z.shape[:-1]
         x = z.reshape(-1, z.shape[-1])
         logdet = torch.zeros(x.shape[0], device=z.device, dtype=z.dtype)

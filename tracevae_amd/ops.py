@@ -15,7 +15,8 @@ from . import hip
 __all__ = [
     'DeviceGraph', 'TIMER', 'gemm', 'linear', 'matmul_nn', 'rowdot', 'colsum', 'gat_conv', 'bn_lrelu',
     'graph_sum', 'segment_mean', 'embedding', 'latdec_input', 'latdec_rows', 'adj_bernoulli_ll',
-    'categorical_ll', 'normal_reparam', 'normal_ll', 'latency_ll', 'score_reduce',
+    'categorical_ll', 'normal_reparam', 'normal_ll', 'realnvp_log_prob', 'realnvp_supported',
+    'latency_ll', 'score_reduce',
     'LATENCY_MODES',
 ]
 
@@ -726,6 +727,71 @@ def normal_ll(x, mean, logstd_raw, lo=None, hi=None):
     """sum over the last axis of Normal(x; mean, clamp(logstd_raw)); all three same shape."""
     lo, hi = _bounds(lo, hi)
     return _NormalLL.apply(x, mean, logstd_raw, lo, hi)
+
+
+class _RealNVPLogProb(Function):
+    @staticmethod
+    def forward(ctx, z, levels: int, hidden: int, slope: float, *params):
+        import ctypes
+        z = _check(z, 'z')
+        dim = z.shape[-1]
+        rows = z.numel() // dim
+        params = [_check(p, 'flow parameter') for p in params]
+        if len(params) != 9 * levels:
+            raise ValueError(f'expected {9 * levels} flow parameters, got {len(params)}')
+        n1 = dim // 2
+        shapes = [(dim,), (dim,), (hidden, n1), (hidden,), (dim - n1, hidden), (dim - n1,),
+                  (dim - n1, hidden), (dim - n1,), (dim, dim)]
+        for i, p in enumerate(params):
+            if tuple(p.shape) != shapes[i % 9]:
+                raise ValueError(f'flow parameter {i % 9} of level {i // 9} has shape '
+                                 f'{tuple(p.shape)}, expected {shapes[i % 9]}')
+        size = hip.query('tv_realnvp_workspace_floats', rows, levels, dim, hidden)
+        if size < 0:
+            raise hip.HipLibraryError(f'no RealNVP kernel for dim {dim} / hidden {hidden} / '
+                                      f'{levels} levels')
+        ws = torch.empty([size], dtype=_f32, device=z.device)
+        table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        logp = torch.empty(z.shape[:-1], dtype=_f32, device=z.device)
+        with TIMER.region('realnvp_fwd', 0.0):
+            hip.call('tv_realnvp_logprob_fwd', rows, levels, dim, hidden, slope, hip.ptr(z), table,
+                     hip.ptr(ws), hip.ptr(logp))
+        ctx.save_for_backward(z, ws, *params)
+        ctx.args = (rows, levels, dim, hidden, slope)
+        return logp
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dlogp):
+        import ctypes
+        z, ws, *params = ctx.saved_tensors
+        rows, levels, dim, hidden, slope = ctx.args
+        dlogp = _check(dlogp, 'dlogp')
+        need = ctx.needs_input_grad[4:]
+        packed = torch.empty([sum(p.numel() for p in params)], dtype=_f32, device=z.device)
+        grads, ptrs, off = [], [], 0
+        for p, wanted in zip(params, need):
+            view = packed[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+            grads.append(view if wanted else None)
+            ptrs.append(view.data_ptr() if wanted else None)
+        dz = torch.empty_like(z)
+        table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        gtable = (ctypes.c_void_p * len(params))(*ptrs)
+        with TIMER.region('realnvp_bwd', 0.0):
+            hip.call('tv_realnvp_logprob_bwd', rows, levels, dim, hidden, slope, hip.ptr(z), table,
+                     hip.ptr(dlogp), hip.ptr(ws), hip.ptr(dz), gtable)
+        return (dz if ctx.needs_input_grad[0] else None, None, None, None) + tuple(grads)
+
+
+def realnvp_supported(dim: int, hidden: int, levels: int) -> bool:
+    return 1 <= levels <= 8 and bool(hip.query('tv_realnvp_supported', dim, hidden))
+
+
+def realnvp_log_prob(z, params, levels: int, hidden: int, slope: float):
+    """log p(z) of the RealNVP prior, z [..., dim]; `params`: 9 tensors per level in the order
+    of `tv_realnvp_logprob_fwd` (include/tracevae_hip.h)."""
+    return _RealNVPLogProb.apply(z, levels, hidden, slope, *params)
 
 
 LATENCY_MODES = {'normal': 0, 'safe': 1, 'biased': 2, 'anomaly': 3}
