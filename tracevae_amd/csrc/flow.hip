@@ -5,9 +5,10 @@
 // the whole flow of a row fits one lane's registers, so forward and backward are one kernel each
 // instead of ~300 tiny launches.
 //
-//   prepare : one lane per level - log|det K| and K^-T by Gauss-Jordan in float64 (parameter
-//             only, shared by every row)
-//   forward : one lane per row
+//   prepare : one wave per level - log|det K| and K^-T by Gauss-Jordan in float64, a lane per
+//             column (parameter only, shared by every row)
+//   forward : one lane per row; a level's parameters are staged in LDS and read at
+//             wave-uniform addresses
 //   backward: a 256-lane workgroup per 64 rows.  Wave 0 recomputes the forward pass (level inputs
 //             kept in LDS), walks the levels backwards and stages the per-row factors of every
 //             parameter gradient in LDS; all four waves then sum the outer products over the 64
@@ -39,97 +40,178 @@ __host__ __device__ inline int64_t flow_header_floats(int levels, int dim) {
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void flow_prepare_kernel(int levels, int dim, FlowPtrs fp, float *ws) {
-  const int l = threadIdx.x;
-  if (l >= levels) return;
+// one 64-lane workgroup per level, lane j owns column j of [K | I] (kept in LDS as float64)
+__global__ __launch_bounds__(64) void flow_prepare_kernel(int levels, int dim, FlowPtrs fp,
+                                                          float *ws) {
   constexpr int MD = TV_FLOW_MAX_DIM;
-  double a[MD][2 * MD];
+  __shared__ double a[MD][2 * MD + 1];
+  __shared__ double colc[MD];
+  __shared__ int s_piv;
+  const int l = blockIdx.x, j = threadIdx.x, w = 2 * dim;
   const float *k = fp.p[l][8];
-  for (int i = 0; i < dim; ++i)
-    for (int j = 0; j < dim; ++j) {
-      a[i][j] = (double)k[i * dim + j];
-      a[i][dim + j] = i == j ? 1.0 : 0.0;
-    }
+  if (j < w)
+    for (int i = 0; i < dim; ++i)
+      a[i][j] = j < dim ? (double)k[i * dim + j] : (j - dim == i ? 1.0 : 0.0);
+  __syncthreads();
   double logdet = 0.0;
   for (int c = 0; c < dim; ++c) {
-    int piv = c;
-    for (int r = c + 1; r < dim; ++r)
-      if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-    if (piv != c)
-      for (int j = 0; j < 2 * dim; ++j) {
-        const double t = a[c][j];
-        a[c][j] = a[piv][j];
-        a[piv][j] = t;
-      }
+    if (j == 0) {
+      int piv = c;
+      for (int r = c + 1; r < dim; ++r)
+        if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+      s_piv = piv;
+    }
+    __syncthreads();
+    const int piv = s_piv;
+    if (j < w && piv != c) {
+      const double t = a[c][j];
+      a[c][j] = a[piv][j];
+      a[piv][j] = t;
+    }
+    __syncthreads();
     const double d = a[c][c];
+    if (j < dim) colc[j] = a[j][c];
+    __syncthreads();
     logdet += log(fabs(d));
-    const double inv = 1.0 / d;
-    for (int j = 0; j < 2 * dim; ++j) a[c][j] *= inv;
-    for (int r = 0; r < dim; ++r) {
-      if (r == c) continue;
-      const double f = a[r][c];
-      if (f != 0.0)
-        for (int j = 0; j < 2 * dim; ++j) a[r][j] -= f * a[c][j];
+    if (j < w) {
+      const double pc = a[c][j] / d;
+      for (int r = 0; r < dim; ++r)
+        if (r != c) a[r][j] -= colc[r] * pc;
+      a[c][j] = pc;
+    }
+    __syncthreads();
+  }
+  if (j == 0) ws[l] = (float)logdet;
+  float *inv_t = ws + levels + (int64_t)l * dim * dim;
+  if (j < dim)
+    for (int i = 0; i < dim; ++i) inv_t[i * dim + j] = (float)a[j][dim + i];   // (K^-1)^T
+}
+
+// LDS image of one level's parameters.  The hidden layer is stored as one record per hidden
+// unit k - {b1[k], w1[k][:], ws[:][k], wp[:][k]} padded to a multiple of 4 floats - so the k
+// loops fetch a unit's 16 coefficients with four 16-byte LDS reads at a wave-uniform address.
+template <int D, int H>
+struct LdsW {
+  using X = Dims<D, H>;
+  static constexpr int RW = (1 + X::N1 + 2 * X::N2 + 3) / 4 * 4;
+  static constexpr int L_REC = 0, L_AB = H * RW, L_AS = L_AB + D, L_BS = L_AS + D,
+                       L_BP = L_BS + X::N2, L_K = (L_BP + X::N2 + 3) / 4 * 4,
+                       SIZE = (L_K + D * D + 3) / 4 * 4;
+  __device__ static constexpr int dest(int q, int e) {
+    return q == 0 ? L_AB + e
+         : q == 1 ? L_AS + e
+         : q == 2 ? (e / X::N1) * RW + 1 + e % X::N1
+         : q == 3 ? e * RW
+         : q == 4 ? (e % H) * RW + 1 + X::N1 + e / H
+         : q == 5 ? L_BS + e
+         : q == 6 ? (e % H) * RW + 1 + X::N1 + X::N2 + e / H
+         : q == 7 ? L_BP + e
+                  : L_K + e;
+  }
+};
+
+// every lane of the workgroup takes part; trip counts are compile-time, so every load of the
+// level is issued before the first LDS store waits for it
+template <int D, int H, int NT>
+__device__ __forceinline__ void stage_level(const float *const *p, float *w, int t) {
+  using X = Dims<D, H>;
+  using L = LdsW<D, H>;
+  constexpr int len[NP] = {D, D, H * X::N1, H, X::N2 * H, X::N2, X::N2 * H, X::N2, D * D};
+  constexpr int TRIPS = (H * X::N2 + NT - 1) / NT;
+  float v[NP][TRIPS];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const float *src = p[q];
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i)
+      if (i * NT < len[q]) {
+        const int e = i * NT + t;
+        v[q][i] = e < len[q] ? src[e] : 0.f;
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i)
+      if (i * NT < len[q]) {
+        const int e = i * NT + t;
+        if (e < len[q]) w[L::dest(q, e)] = v[q][i];
+      }
+}
+
+template <int RW>
+__device__ __forceinline__ void load_record(const float *w, int k, float (&r)[RW]) {
+  const float4 *src = reinterpret_cast<const float4 *>(w + k * RW);
+#pragma unroll
+  for (int q = 0; q < RW / 4; ++q) {
+    const float4 v = src[q];
+    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+  }
+}
+
+// exp / softplus on the hardware exp2 / log2 (the flow's terms are O(1); 1e-6 is plenty)
+__device__ __forceinline__ float flow_softplus(float x) {
+  return fmaxf(x, 0.f) + __logf(1.0f + __expf(-fabsf(x)));
+}
+
+// y = K x with K [D, D] read as 16-byte pieces
+template <int D, bool TRANSPOSED>
+__device__ __forceinline__ void dense_apply(const float *kk, const float (&x)[D], float (&y)[D]) {
+  static_assert(D * D % 4 == 0, "dense kernel is read as float4");
+#pragma unroll
+  for (int i = 0; i < D; ++i) y[i] = 0.f;
+  const float4 *k4 = reinterpret_cast<const float4 *>(kk);
+#pragma unroll
+  for (int q = 0; q < D * D / 4; ++q) {
+    const float4 v = k4[q];
+    const float c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = 4 * q + j, row = e / D, col = e % D;
+      if (TRANSPOSED) y[col] = fmaf(c[j], x[row], y[col]);
+      else y[row] = fmaf(c[j], x[col], y[row]);
     }
   }
-  ws[l] = (float)logdet;
-  float *inv_t = ws + levels + (int64_t)l * dim * dim;
-  for (int i = 0; i < dim; ++i)
-    for (int j = 0; j < dim; ++j) inv_t[i * dim + j] = (float)a[j][dim + i];   // (K^-1)^T
 }
 
 // one level forward on a row held in registers; returns the row's log-det contribution
 template <int D, int H>
-__device__ __forceinline__ float level_forward(const float *const *p, float slope, float (&x)[D]) {
+__device__ __forceinline__ float level_forward(const float *w, float slope, float (&x)[D]) {
   using X = Dims<D, H>;
-  constexpr int N1 = X::N1, N2 = X::N2;
-  const float *ab = p[0], *as = p[1], *w1 = p[2], *b1 = p[3], *ws = p[4], *bs = p[5], *wp = p[6],
-              *bp = p[7], *kk = p[8];
+  using L = LdsW<D, H>;
+  constexpr int N1 = X::N1, N2 = X::N2, RW = L::RW;
+  const float *ab = w + L::L_AB, *as = w + L::L_AS, *bs = w + L::L_BS, *bp = w + L::L_BP;
 #pragma unroll
-  for (int j = 0; j < D; ++j) x[j] = (x[j] + ab[j]) * expf(as[j]);
+  for (int j = 0; j < D; ++j) x[j] = (x[j] + ab[j]) * __expf(as[j]);
   float sh[N2], pr[N2];
 #pragma unroll
   for (int i = 0; i < N2; ++i) { sh[i] = bs[i]; pr[i] = bp[i]; }
+#pragma unroll 4
   for (int k = 0; k < H; ++k) {
-    float a = b1[k];
+    float r[RW];
+    load_record<RW>(w, k, r);
+    float a = r[0];
 #pragma unroll
-    for (int i = 0; i < N1; ++i) a = fmaf(w1[k * N1 + i], x[i], a);
+    for (int i = 0; i < N1; ++i) a = fmaf(r[1 + i], x[i], a);
     const float h = tv_lrelu(a, slope);
 #pragma unroll
     for (int i = 0; i < N2; ++i) {
-      sh[i] = fmaf(ws[i * H + k], h, sh[i]);
-      pr[i] = fmaf(wp[i * H + k], h, pr[i]);
+      sh[i] = fmaf(r[1 + N1 + i], h, sh[i]);
+      pr[i] = fmaf(r[1 + N1 + N2 + i], h, pr[i]);
     }
   }
   float ld = 0.f;
 #pragma unroll
   for (int i = 0; i < N2; ++i) {
-    const float ls = -tv_softplus(-(pr[i] + 2.0f));     // logsigmoid(pre + 2)
-    x[N1 + i] = (x[N1 + i] + sh[i]) * expf(ls);
+    const float ls = -flow_softplus(-(pr[i] + 2.0f));     // logsigmoid(pre + 2)
+    x[N1 + i] = (x[N1 + i] + sh[i]) * __expf(ls);
     ld += ls;
   }
   float y[D];
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < D; ++j) acc = fmaf(kk[i * D + j], x[j], acc);
-    y[i] = acc;
-  }
+  dense_apply<D, false>(w + L::L_K, x, y);
 #pragma unroll
   for (int i = 0; i < D; ++i) x[i] = y[i];
   return ld;
-}
-
-__device__ __forceinline__ float flow_constant(int levels, int dim, const FlowPtrs &fp,
-                                               const float *ws) {
-  float c = 0.f;
-  for (int l = 0; l < levels; ++l) {
-    c += ws[l];
-    const float *as = fp.p[l][1];
-    for (int j = 0; j < dim; ++j) c += as[j];
-  }
-  return c;
 }
 
 template <int D, int H>
@@ -137,17 +219,27 @@ __global__ __launch_bounds__(64) void flow_fwd_kernel(int64_t rows, int levels, 
                                                       const float *__restrict__ z, FlowPtrs fp,
                                                       const float *__restrict__ ws,
                                                       float *__restrict__ logp) {
-  const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (r >= rows) return;
+  using X = Dims<D, H>;
+  __shared__ __align__(16) float s_w[LdsW<D, H>::SIZE];
+  const int t = threadIdx.x;
+  const int64_t r = (int64_t)blockIdx.x * 64 + t;
+  const bool valid = r < rows;
   float x[D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) x[j] = z[r * D + j];
+  for (int j = 0; j < D; ++j) x[j] = valid ? z[r * D + j] : 0.f;
   float ld = 0.f;
-  for (int l = 0; l < levels; ++l) ld += level_forward<D, H>(fp.p[l], slope, x);
+  for (int l = 0; l < levels; ++l) {
+    __syncthreads();
+    stage_level<D, H, 64>(fp.p[l], s_w, t);
+    __syncthreads();
+    ld += level_forward<D, H>(s_w, slope, x) + ws[l];
+#pragma unroll
+    for (int j = 0; j < D; ++j) ld += s_w[LdsW<D, H>::L_AS + j];     // ActNorm log-det: sum(pre_scale)
+  }
   float base = 0.f;
 #pragma unroll
   for (int j = 0; j < D; ++j) base += -0.5f * LOG_2PI - 0.5f * x[j] * x[j];
-  logp[r] = base + ld + flow_constant(levels, D, fp, ws);
+  if (valid) logp[r] = base + ld;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -160,12 +252,16 @@ __global__ __launch_bounds__(256) void flow_bwd_kernel(int64_t rows, int levels,
                                                        float *__restrict__ dz,
                                                        float *__restrict__ partial) {
   using X = Dims<D, H>;
-  constexpr int N1 = X::N1, N2 = X::N2, P = X::P;
-  extern __shared__ float lds[];
+  using L = LdsW<D, H>;
+  constexpr int N1 = X::N1, N2 = X::N2, P = X::P, RW = L::RW;
+  constexpr int STAGE_FLOATS = (2 * H + 2 * N2 + 4 * D) * RS;
+  extern __shared__ __align__(16) float lds[];
   // staging (per level): h[H], da[H], dsh[N2], dpr[N2], u[D], dxn[D], dyb[D], dys[D]; then xs
   float *s_h = lds, *s_da = s_h + H * RS, *s_dsh = s_da + H * RS, *s_dpr = s_dsh + N2 * RS,
         *s_u = s_dpr + N2 * RS, *s_dxn = s_u + D * RS, *s_dyb = s_dxn + D * RS,
-        *s_dys = s_dyb + D * RS, *s_xs = s_dys + D * RS;     // xs[levels][D][64]
+        *s_dys = s_dyb + D * RS,
+        *s_w = lds + (STAGE_FLOATS + 3) / 4 * 4,             // LdsW image of a level
+        *s_xs = s_w + L::SIZE;                               // xs[levels][D][64]
   const int t = threadIdx.x;
   const int64_t r = (int64_t)blockIdx.x * 64 + t;
   const bool lead = t < 64;
@@ -176,39 +272,52 @@ __global__ __launch_bounds__(256) void flow_bwd_kernel(int64_t rows, int levels,
 #pragma unroll
     for (int j = 0; j < D; ++j) x[j] = valid ? z[r * D + j] : 0.f;
     g = valid ? dlogp[r] : 0.f;
-    for (int l = 0; l < levels; ++l) {
+  }
+  for (int l = 0; l < levels; ++l) {
+    __syncthreads();
+    stage_level<D, H, 256>(fp.p[l], s_w, t);
+    __syncthreads();
+    if (lead) {
 #pragma unroll
       for (int j = 0; j < D; ++j) s_xs[(l * D + j) * 64 + t] = x[j];
-      level_forward<D, H>(fp.p[l], slope, x);
+      level_forward<D, H>(s_w, slope, x);
     }
+  }
+  if (lead) {
 #pragma unroll
     for (int j = 0; j < D; ++j) dx[j] = -x[j] * g;
   }
   float *out = partial + (int64_t)blockIdx.x * ((int64_t)levels * P + 1);
   for (int l = levels - 1; l >= 0; --l) {
-    const float *const *p = fp.p[l];
+    if (l != levels - 1) {             // the last level's parameters are still staged
+      stage_level<D, H, 256>(fp.p[l], s_w, t);
+      __syncthreads();
+    }
     if (lead) {
-      const float *ab = p[0], *as = p[1], *w1 = p[2], *b1 = p[3], *ws = p[4], *bs = p[5],
-                  *wp = p[6], *bp = p[7], *kk = p[8];
+      const float *ab = s_w + L::L_AB, *as = s_w + L::L_AS, *bs = s_w + L::L_BS,
+                  *bp = s_w + L::L_BP, *kk = s_w + L::L_K;
       float y[D], es[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        es[j] = expf(as[j]);
+        es[j] = __expf(as[j]);
         y[j] = (s_xs[(l * D + j) * 64 + t] + ab[j]) * es[j];
       }
       float sh[N2], pr[N2];
 #pragma unroll
       for (int i = 0; i < N2; ++i) { sh[i] = bs[i]; pr[i] = bp[i]; }
+#pragma unroll 4
       for (int k = 0; k < H; ++k) {
-        float a = b1[k];
+        float r[RW];
+        load_record<RW>(s_w, k, r);
+        float a = r[0];
 #pragma unroll
-        for (int i = 0; i < N1; ++i) a = fmaf(w1[k * N1 + i], y[i], a);
+        for (int i = 0; i < N1; ++i) a = fmaf(r[1 + i], y[i], a);
         const float h = tv_lrelu(a, slope);
         s_h[k * RS + t] = h;
 #pragma unroll
         for (int i = 0; i < N2; ++i) {
-          sh[i] = fmaf(ws[i * H + k], h, sh[i]);
-          pr[i] = fmaf(wp[i * H + k], h, pr[i]);
+          sh[i] = fmaf(r[1 + N1 + i], h, sh[i]);
+          pr[i] = fmaf(r[1 + N1 + N2 + i], h, pr[i]);
         }
       }
       float sg[N2], u[D];
@@ -216,17 +325,14 @@ __global__ __launch_bounds__(256) void flow_bwd_kernel(int64_t rows, int levels,
       for (int i = 0; i < N1; ++i) u[i] = y[i];
 #pragma unroll
       for (int i = 0; i < N2; ++i) {
-        sg[i] = expf(-tv_softplus(-(pr[i] + 2.0f)));
+        sg[i] = __expf(-flow_softplus(-(pr[i] + 2.0f)));
         u[N1 + i] = (y[N1 + i] + sh[i]) * sg[i];
       }
       // invertible dense: xn = K u
       float du[D];
+      dense_apply<D, true>(kk, dx, du);
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < D; ++i) acc = fmaf(kk[i * D + j], dx[i], acc);
-        du[j] = acc;
         s_u[j * RS + t] = u[j];
         s_dxn[j * RS + t] = dx[j];
       }
@@ -243,17 +349,20 @@ __global__ __launch_bounds__(256) void flow_bwd_kernel(int64_t rows, int levels,
       }
 #pragma unroll
       for (int i = 0; i < N1; ++i) dy[i] = du[i];
+#pragma unroll 4
       for (int k = 0; k < H; ++k) {
         float dh = 0.f;
+        float r[RW];
+        load_record<RW>(s_w, k, r);
 #pragma unroll
         for (int i = 0; i < N2; ++i) {
-          dh = fmaf(ws[i * H + k], dsh[i], dh);
-          dh = fmaf(wp[i * H + k], dpr[i], dh);
+          dh = fmaf(r[1 + N1 + i], dsh[i], dh);
+          dh = fmaf(r[1 + N1 + N2 + i], dpr[i], dh);
         }
         const float da = s_h[k * RS + t] > 0.f ? dh : dh * slope;
         s_da[k * RS + t] = da;
 #pragma unroll
-        for (int i = 0; i < N1; ++i) dy[i] = fmaf(w1[k * N1 + i], da, dy[i]);
+        for (int i = 0; i < N1; ++i) dy[i] = fmaf(r[1 + i], da, dy[i]);
       }
       // act-norm: y = (x + b) * exp(s); the constant sum(s) of log p adds g to every ds
 #pragma unroll
@@ -333,7 +442,8 @@ __global__ __launch_bounds__(256) void flow_grad_reduce_kernel(int levels, int64
 template <int D, int H>
 int64_t bwd_lds_bytes(int levels) {
   using X = Dims<D, H>;
-  return (int64_t)sizeof(float) * ((2 * H + 2 * X::N2 + 4 * D) * RS + (int64_t)levels * D * 64);
+  return (int64_t)sizeof(float) * (((2 * H + 2 * X::N2 + 4 * D) * RS + 3) / 4 * 4 +
+                                   LdsW<D, H>::SIZE + (int64_t)levels * D * 64);
 }
 
 int check_dims(const char *who, int64_t rows, int levels, int dim, int hidden) {
@@ -357,7 +467,7 @@ int fill_ptrs(const char *who, int levels, const float *const *params, FlowPtrs 
 template <int D, int H>
 int run_fwd(int64_t rows, int levels, float slope, const float *z, const FlowPtrs &fp, float *ws,
             float *logp, hipStream_t s) {
-  hipLaunchKernelGGL(flow_prepare_kernel, dim3(1), dim3(64), 0, s, levels, D, fp, ws);
+  hipLaunchKernelGGL(flow_prepare_kernel, dim3(levels), dim3(64), 0, s, levels, D, fp, ws);
   TV_LAUNCH_CHECK("tv_realnvp_logprob_fwd(prepare)");
   if (rows == 0) return TV_OK;
   hipLaunchKernelGGL((flow_fwd_kernel<D, H>), dim3((unsigned)tv_cdiv(rows, 64)), dim3(64), 0, s, rows,
