@@ -120,6 +120,21 @@ int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const
                 int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc,
                 const float *bias, const float *row_scale, int accumulate, void *workspace,
                 int64_t workspace_bytes, void *stream);
+/* The same product with BatchNorm + LeakyReLU applied to one operand on its way into LDS, so the
+ * activation between two layers (model/gnn_layers.py:152-155 feeding the next GATConv.fc,
+ * gnn_layers.py:134-143) is never written to memory:
+ *   act_operand 1: A (needs trans_a = 0), A[m,k] -> lrelu(A[m,k] * act_scale[k] + act_shift[k])
+ *                  - the forward product  ft = act(x) . W^T
+ *   act_operand 2: B (needs trans_b = 0), B[k,n] -> lrelu(B[k,n] * act_scale[n] + act_shift[n])
+ *                  - the weight gradient  dW = dft^T . act(x)
+ *   act_operand 0: plain tv_gemm_f32.
+ * act_scale / act_shift: 16-byte aligned device vectors (tv_bn_finalize_coeffs writes them).
+ * Same workspace rule as tv_gemm_f32. */
+int tv_gemm_f32_act(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
+                    int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc,
+                    const float *bias, const float *row_scale, int accumulate, int act_operand,
+                    const float *act_scale, const float *act_shift, float act_slope,
+                    void *workspace, int64_t workspace_bytes, void *stream);
 
 /* skinny right-hand side (N <= 8): out[r,j] = row_scale[r] * sum_k x[r,k] w[k,j]  (w is [K,N])
  * Replaces the 1000->2 GraphConv matmul of the latency decoder (model/latency_vae.py:221-229,
@@ -181,6 +196,8 @@ int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
  *                        (row r counts row_weight[r] times when row_weight != NULL)
  *   tv_bn_finalize     : mean, rstd (biased variance) from the partials, in float64;
  *                        running_mean/var updated with `momentum` (unbiased variance)
+ *   tv_bn_finalize_coeffs: the same, plus scale = gamma*rstd, shift = beta - mean*scale
+ *                        (the folded form tv_gemm_f32_act / tv_affine_lrelu apply)
  *   tv_bn_apply_lrelu  : y = LeakyReLU_slope((x-mean)*rstd*gamma + beta)
  *   tv_affine_lrelu    : y = LeakyReLU_slope(x*scale + shift)   (eval mode, folded stats)
  *   tv_bn_eval_coeffs  : scale = gamma/sqrt(var+eps), shift = beta - mean*scale
@@ -194,6 +211,10 @@ int tv_colstats(int64_t rows, int64_t cols, const float *x, const float *row_wei
 int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, int64_t count, float eps,
                    float momentum, float *mean, float *rstd, float *running_mean,
                    float *running_var, void *stream);
+int tv_bn_finalize_coeffs(int64_t cols, int64_t nblk, const float *partial, int64_t count,
+                          float eps, float momentum, float *mean, float *rstd,
+                          float *running_mean, float *running_var, const float *gamma,
+                          const float *beta, float *scale, float *shift, void *stream);
 int tv_bn_apply_lrelu(int64_t rows, int64_t cols, const float *x, const float *mean,
                       const float *rstd, const float *gamma, const float *beta, float slope,
                       float *y, void *stream);

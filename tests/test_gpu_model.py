@@ -332,3 +332,41 @@ def test_learning_rate_schedule_follows_the_finished_epoch_count(device):
     assert all(p.requires_grad == n.startswith('latency_vae.') for n, p in vae.named_parameters())
     trainer.set_phase(latency_only=False)
     assert all(p.requires_grad for p in vae.parameters())
+
+
+def test_deferred_batch_norm_equals_materialised(device, monkeypatch):
+    """Training step with BatchNorm + LeakyReLU applied inside the next layer's GEMMs
+    (`_DeferredBN`) against the same step with every activation materialised: loss, every
+    gradient, running statistics and batch counters."""
+    import tracevae_amd.model as model
+    from tracevae_amd.batch import TraceGraphBatch
+    V, M = 60, 16
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 3, 12, seed=21)
+    vae.train()
+    B = len(flat)
+    g = torch.Generator().manual_seed(3)
+    eps = {'z': torch.randn(B, 10, generator=g), 'z2': torch.randn(B, 10, generator=g)}
+    state = {k: v.clone() for k, v in vae.state_dict().items()}
+    results = {}
+    for fused in (True, False):
+        monkeypatch.setattr(model, 'FUSED_BN_LINEAR', fused)
+        vae.load_state_dict(state)
+        vae.zero_grad()
+        G = TraceGraphBatch.from_store(store, np.arange(B), M)
+        chain = vae.q(G, eps=eps).chain(vae.p, G=G)
+        loss = chain.vi.training.sgvb().mean()
+        loss.backward()
+        results[fused] = dict(
+            loss=loss.detach().clone(),
+            grads={n: p.grad.clone() for n, p in vae.named_parameters() if p.grad is not None},
+            stats={k: v.clone() for k, v in vae.state_dict().items()
+                   if 'running_' in k or 'num_batches' in k})
+    a, b = results[True], results[False]
+    assert rel_err(a['loss'], b['loss']) < 1e-5
+    for k in b['stats']:
+        assert rel_err(a['stats'][k].float(), b['stats'][k].float()) < 1e-5, k
+    assert set(a['grads']) == set(b['grads'])
+    gmax = max(float(v.abs().max()) for v in b['grads'].values())
+    for n, want in b['grads'].items():
+        scale = max(float(want.abs().max()), 1e-4 * gmax)
+        assert float((a['grads'][n] - want).abs().max()) / scale < 1e-3, n

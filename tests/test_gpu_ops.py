@@ -640,3 +640,80 @@ def test_realnvp_k_samples_frozen_parameters_and_fallback(device):
         ops.realnvp_log_prob(z, params[:-1], levels, hidden, 0.01)
     with pytest.raises(ValueError):
         ops.realnvp_log_prob(torch.randn(4, 10, device=device), [params[1]] + params[1:], 5, 32, 0.01)
+
+
+# ---------------------------------------------------------------------------------------
+# BatchNorm + LeakyReLU inside the GEMM (tv_gemm_f32_act) and the fused layer operator
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('m,n,k,ta,tb,operand', [
+    (300, 200, 96, False, True, 1),        # forward product shape: act(x) . W^T
+    (257, 130, 77, False, True, 1),        # nothing aligned: 4-byte loads, partial k-tile
+    (128, 128, 1000, False, False, 1),     # A prologue with a k-major B
+    (1000, 1000, 5000, True, False, 2),    # weight gradient: split over K
+    (64, 100, 333, True, False, 2),        # odd sizes, B prologue
+    (200, 72, 130, False, False, 2),       # B prologue with a row-major A
+    (51200, 1000, 1000, False, True, 1),   # the layer shape of the bench (tail split)
+])
+def test_gemm_act_prologue(device, m, n, k, ta, tb, operand):
+    from tracevae_amd import ops
+    gen = torch.Generator(device='cpu').manual_seed(m + n + k)
+    a = torch.randn((k, m) if ta else (m, k), generator=gen).to(device)
+    b = torch.randn((n, k) if tb else (k, n), generator=gen).to(device)
+    feats = k if operand == 1 else n
+    scale = (0.5 + torch.rand(feats, generator=gen)).to(device)
+    shift = (0.3 * torch.randn(feats, generator=gen)).to(device)
+    bias = torch.randn(n, generator=gen).to(device)
+    got = ops.gemm(a, b, ta, tb, bias=bias, act=(operand, scale, shift, 0.01))
+    A = (a.t() if ta else a).double()
+    Bm = (b.t() if tb else b).double()
+    if operand == 1:
+        A = F.leaky_relu(A * scale.double() + shift.double(), 0.01)
+    else:
+        Bm = F.leaky_relu(Bm * scale.double() + shift.double(), 0.01)
+    want = A @ Bm + bias.double()
+    assert rel_err(got, want) < 2e-5
+
+
+def test_gemm_act_refuses_bad_arguments(device):
+    from tracevae_amd import hip, ops
+    a = torch.randn(64, 32, device=device)
+    b = torch.randn(32, 48, device=device)
+    s = torch.ones(32, device=device)
+    with pytest.raises(hip.HipLibraryError):      # A prologue on a transposed A
+        ops.gemm(a.t().contiguous(), b, True, False, act=(1, s, s, 0.01))
+    with pytest.raises(hip.HipLibraryError):      # B prologue on a transposed B
+        ops.gemm(a, b.t().contiguous(), False, True, act=(2, torch.ones(48, device=device),
+                                                          torch.ones(48, device=device), 0.01))
+    with pytest.raises(ValueError):               # wrong vector length
+        ops.gemm(a, b, False, False, act=(1, torch.ones(31, device=device), s, 0.01))
+
+
+@pytest.mark.parametrize('rows,cols,out,weighted', [(700, 96, 64, False), (333, 50, 37, False),
+                                                    (900, 128, 200, True)])
+def test_bn_lrelu_linear_equals_composition(device, rows, cols, out, weighted):
+    """The fused operator against bn_lrelu followed by linear: values, all four gradients and
+    the running statistics."""
+    from tracevae_amd import ops
+    gen = torch.Generator(device='cpu').manual_seed(rows + cols)
+    x0 = (torch.randn(rows, cols, generator=gen) * 2 + 0.5).to(device)
+    w0 = (torch.randn(out, cols, generator=gen) / cols ** 0.5).to(device)
+    g0 = (0.5 + torch.rand(cols, generator=gen)).to(device)
+    b0 = (0.2 * torch.randn(cols, generator=gen)).to(device)
+    dft = torch.randn(rows, out, generator=gen).to(device)
+    rw = count = None
+    if weighted:
+        rw = torch.ones(rows, device=device)
+        rw[-50:] = torch.randint(1, 9, (50,), generator=gen).float().to(device)
+        count = int(rw.sum().item())
+    res = []
+    for fused in (True, False):
+        x, w, g, b = (t.clone().requires_grad_(True) for t in (x0, w0, g0, b0))
+        rm, rv = torch.zeros(cols, device=device), torch.ones(cols, device=device)
+        if fused:
+            ft = ops.bn_lrelu_linear(x, g, b, w, rm, rv, 1e-6, 0.1, 0.01, None, rw, count)
+        else:
+            ft = ops.linear(ops.bn_lrelu(x, g, b, rm, rv, True, 1e-6, 0.1, 0.01, None, rw, count), w)
+        ft.backward(dft)
+        res.append((ft.detach(), x.grad, g.grad, b.grad, w.grad, rm, rv))
+    for i, name in enumerate(('ft', 'dx', 'dgamma', 'dbeta', 'dw', 'running_mean', 'running_var')):
+        assert rel_err(res[0][i], res[1][i]) < 2e-5, name

@@ -52,6 +52,10 @@ struct GemmArgs {
   float *tail_slabs;
   int accumulate;
   int a_vec, b_vec;          // 16-byte loads allowed for the operand (host-side dispatch)
+  // operand prologue (tv_gemm_f32_act): v -> lrelu(v * act_scale[f] + act_shift[f]) on the way
+  // into LDS, f = the operand's feature index (k for a row-major A, n for a k-major B)
+  const float *act_scale, *act_shift;
+  float act_slope;
 };
 
 // Staging of one operand tile: 128 (x) by 32 (k) floats, 16 floats per thread.
@@ -63,10 +67,20 @@ struct GemmArgs {
 //   [k][x] VEC:    float4 it: k = (t>>5) + 8*it,  x = (t&31)*4 ..+3
 //   [x][k] scalar: element i: x = (t>>5) + 8*i,   k = t&31
 //   [k][x] scalar: element i: k = (t>>7) + 2*i,   x = t&127
-template <bool KX, bool VEC>
+//   ACT = the operand goes through lrelu(v * scale[f] + shift[f]) before it is stored to LDS;
+//         f = k for an [x][k] operand (scale/shift follow the k-tiles), f = x for a [k][x] one
+//         (fixed per thread).  Elements of the zero-filled part of a partial k-tile stay zero
+//         for f = k; for f = x they become lrelu(shift), harmless because the other operand's
+//         zero-filled k rows multiply them.
+template <bool KX, bool VEC, bool ACT>
 struct Stage {
   static constexpr int NL = VEC ? 4 : 16;
+  static constexpr int NF = VEC ? 4 : 1;      // features a thread touches
   float r[16];
+  float sc[NF], sh[NF];
+  const float *act_scale, *act_shift;
+  float slope;
+  unsigned fpos;                              // feature index of this thread's first element
   // element offset of load i from the tile origin = min(off0 + i*step, offmax): consecutive
   // loads of a thread are `step` apart (a multiple of ld), and offmax clamps an out-of-range x
   // (rows of an [x][k] operand) onto the last valid row -- such an x only feeds accumulators
@@ -106,10 +120,46 @@ struct Stage {
     }
   }
 
-  __device__ __forceinline__ void advance() { tile += KX ? BK * ld : BK; }
+  __device__ __forceinline__ void init_act(const float *scale, const float *shift, float slope_,
+                                           int64_t x0, int64_t xlim, int64_t k0) {
+    if (!ACT) return;
+    act_scale = scale; act_shift = shift; slope = slope_;
+    if (KX) {
+      // the features are this thread's columns: the same (clamped) x as in init()
+      int x = xlocal(0);
+      if (x0 + x + (VEC ? 3 : 0) >= xlim) x = VEC ? 0 : (int)(xlim - 1 - x0);
+      fpos = (unsigned)(x0 + x);
+      load_act(NF);
+    } else {
+      fpos = (unsigned)(k0 + klocal(0));
+    }
+  }
+
+  // scale / shift of features fpos .. fpos+NF-1; the first `valid` of them exist
+  __device__ __forceinline__ void load_act(int valid) {
+    if (VEC && valid >= NF) {
+      const float4 a = *reinterpret_cast<const float4 *>(act_scale + fpos);
+      const float4 b = *reinterpret_cast<const float4 *>(act_shift + fpos);
+      sc[0] = a.x; sc[NF > 1 ? 1 : 0] = a.y; sc[NF > 2 ? 2 : 0] = a.z; sc[NF > 3 ? 3 : 0] = a.w;
+      sh[0] = b.x; sh[NF > 1 ? 1 : 0] = b.y; sh[NF > 2 ? 2 : 0] = b.z; sh[NF > 3 ? 3 : 0] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const bool ok = j < valid;
+        sc[j] = ok ? act_scale[fpos + j] : 0.f;
+        sh[j] = ok ? act_shift[fpos + j] : 0.f;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void advance() {
+    tile += KX ? BK * ld : BK;
+    if (ACT && !KX) fpos += BK;
+  }
 
   // a full k-tile: unconditional loads
   __device__ __forceinline__ void load() {
+    if (ACT && !KX) load_act(NF);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       if (VEC) {
@@ -123,6 +173,7 @@ struct Stage {
 
   // the partial last k-tile: k >= rem reads the tile's first k instead and is zeroed
   __device__ __forceinline__ void load_tail(int rem) {
+    if (ACT && !KX) load_act(rem - klocal(0));
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int kl = klocal(i);
@@ -137,6 +188,31 @@ struct Stage {
         r[i] = ok ? v : 0.f;
       }
     }
+  }
+
+  // lrelu(y) = max(y, slope*y) for 0 <= slope <= 1 (checked on the host): three VALU ops per
+  // element, written on float2 so that the fma and the multiply become packed-math instructions
+  __device__ __forceinline__ void act2(float &a, float &b, int ja, int jb) const {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 v = {a, b};
+    const f32x2 s2 = {sc[ja], sc[jb]}, h2 = {sh[ja], sh[jb]};
+    const f32x2 y = v * s2 + h2;
+    const f32x2 ys = y * slope;
+    a = fmaxf(y.x, ys.x);
+    b = fmaxf(y.y, ys.y);
+  }
+
+  // the prologue, in registers.  Called after the multiply that follows the loads, so that the
+  // arithmetic sits in the shadow of the MFMAs instead of between the barrier and the LDS stores
+  __device__ __forceinline__ void transform() {
+    transform_half(0);
+    transform_half(1);
+  }
+  __device__ __forceinline__ void transform_half(int h) {
+    if (!ACT) return;
+#pragma unroll
+    for (int i = 8 * h; i < 8 * h + 8; i += 2)
+      act2(r[i], r[i + 1], VEC ? (i & 3) : 0, VEC ? ((i + 1) & 3) : 0);
   }
 
   __device__ __forceinline__ void store(float *s) const {
@@ -168,9 +244,16 @@ __device__ __forceinline__ void read_fragments(const float *s, int w64, int lane
 
 // acc += A-tile . B-tile over `nkb` k-blocks of 8 (FULL: all four, fragments of block kb+1 are
 // read while block kb is multiplied)
-template <bool A_KX, bool B_KX, bool FULL>
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// `hook(kb)` runs after the MFMAs of k-block kb have been issued (the steady-state loop puts the
+// operand prologue of the tile in flight there, in the shadow of the MFMA pipeline)
+template <bool A_KX, bool B_KX, bool FULL, typename Hook = NoHook>
 __device__ __forceinline__ void multiply_tile(const float *as, const float *bs, int wm64, int wn64,
-                                              int lane, int nkb, f32x16 (&acc)[2][2]) {
+                                              int lane, int nkb, f32x16 (&acc)[2][2],
+                                              Hook hook = Hook()) {
   float fa[2][2][4], fb[2][2][4];
   read_fragments<A_KX>(as, wm64, lane, 0, fa[0]);
   read_fragments<B_KX>(bs, wn64, lane, 0, fb[0]);
@@ -189,11 +272,14 @@ __device__ __forceinline__ void multiply_tile(const float *as, const float *bs, 
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][0][s], acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][1][s], acc[1][1], 0, 0, 0);
     }
+    hook(kb);
   }
 }
 
-template <bool A_KX, bool B_KX, bool A_VEC, bool B_VEC>
+// ACT: 0 = plain, 1 = prologue on A (row-major, !A_KX), 2 = prologue on B (k-major, B_KX)
+template <bool A_KX, bool B_KX, bool A_VEC, bool B_VEC, int ACT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+  static_assert(ACT == 0 || (ACT == 1 && !A_KX) || (ACT == 2 && B_KX), "prologue orientation");
   __shared__ __align__(16) float smem[4 * TILE_FLOATS];  // A0 A1 B0 B1
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -245,20 +331,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Stage<A_KX, A_VEC> sa;
-  Stage<B_KX, B_VEC> sb;
+  Stage<A_KX, A_VEC, ACT == 1> sa;
+  Stage<B_KX, B_VEC, ACT == 2> sb;
   sa.init(g.A, g.lda, m0, g.M, kbeg, t);
   sb.init(g.B, g.ldb, n0, g.N, kbeg, t);
+  sa.init_act(g.act_scale, g.act_shift, g.act_slope, m0, g.M, kbeg);
+  sb.init_act(g.act_scale, g.act_shift, g.act_slope, n0, g.N, kbeg);
   float *As = smem, *Bs = smem + 2 * TILE_FLOATS;
 
+  // where the operand prologue runs: after the multiply that follows the loads (default), or
+  // right before the LDS stores (-DTV_ACT_AT_STORE, kept for A/B measurements)
+#ifdef TV_ACT_AT_STORE
+#define TV_POST_LOAD()
+#define TV_PRE_STORE() do { sa.transform(); sb.transform(); } while (0)
+#else
+#define TV_POST_LOAD() do { sa.transform(); sb.transform(); } while (0)
+#define TV_PRE_STORE()
+#endif
   if (nt > 0) {
     if (ntf > 0) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
+    TV_POST_LOAD();
+    TV_PRE_STORE();
     sa.store(As);
     sb.store(Bs);
   }
   if (nt > 1) {
     sa.advance(); sb.advance();
     if (ntf > 1) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
+    TV_POST_LOAD();
   }
 
   // steady state: tiles t, t+1 and t+2 are all full k-tiles, nothing is conditional
@@ -266,18 +366,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   for (; it + 2 < ntf; ++it) {
     const int cur = it & 1;
     __syncthreads();
+    TV_PRE_STORE();
     sa.store(As + (cur ^ 1) * TILE_FLOATS);
     sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
     sa.advance(); sb.advance();
     sa.load(); sb.load();
+    // keep the loads of tile t+2 ahead of the multiply of tile t: left alone, the scheduler
+    // sinks them below the MFMAs (shorter live ranges) and the next iteration then waits for
+    // them right after the barrier
+    __builtin_amdgcn_sched_barrier(0);
+#if defined(TV_ACT_AT_STORE) || defined(TV_ACT_AFTER_MULTIPLY)
     multiply_tile<A_KX, B_KX, true>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
                                     lane, BK / 8, acc);
+    TV_POST_LOAD();
+#else
+    // the prologue of tile t+2 (its loads were issued before this multiply) goes after the
+    // third and fourth k-block, fenced so that it stays between the MFMA groups
+    multiply_tile<A_KX, B_KX, true>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
+                                    lane, BK / 8, acc, [&](int kb) {
+                                      if (ACT != 0 && kb >= 2) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        sa.transform_half(kb - 2);
+                                        sb.transform_half(kb - 2);
+                                        __builtin_amdgcn_sched_barrier(0);
+                                      }
+                                    });
+#endif
   }
   // the last (up to three) tiles: stop staging, the partial k-tile goes through the masked path
   for (; it < nt; ++it) {
     const int cur = it & 1;
     __syncthreads();
     if (it + 1 < nt) {
+      TV_PRE_STORE();
       sa.store(As + (cur ^ 1) * TILE_FLOATS);
       sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
     }
@@ -288,7 +409,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     // only the k-blocks (8 deep) that hold data: all four, fewer in the partial tile
     multiply_tile<A_KX, B_KX, false>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
                                      lane, it < ntf ? BK / 8 : (rem + 7) >> 3, acc);
+    if (it + 2 < nt) TV_POST_LOAD();
   }
+#undef TV_POST_LOAD
+#undef TV_PRE_STORE
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int kh = lane >> 5, xl = lane & 31;
@@ -475,11 +599,12 @@ extern "C" int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) 
   return make_plan(m, n, k).workspace_bytes;
 }
 
-extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k,
-                           const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
-                           int64_t ldc, const float *bias, const float *row_scale,
-                           int accumulate, void *workspace, int64_t workspace_bytes,
-                           void *stream) {
+namespace {
+int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
+             int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, const float *bias,
+             const float *row_scale, int accumulate, int act_operand, const float *act_scale,
+             const float *act_shift, float act_slope, void *workspace, int64_t workspace_bytes,
+             void *stream) {
   TV_REQUIRE(m >= 0 && n >= 0 && k >= 0, "tv_gemm_f32: negative size");
   if (m == 0 || n == 0) return TV_OK;
   TV_REQUIRE(a && b && c, "tv_gemm_f32: null operand");
@@ -498,6 +623,16 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
   g.tail_first = plan.tail_first; g.tail_splits = plan.tail_splits; g.tail_kchunk = plan.tail_kchunk;
   g.slabs = nullptr; g.tail_slabs = nullptr;
   g.accumulate = accumulate;
+  g.act_scale = act_scale; g.act_shift = act_shift; g.act_slope = act_slope;
+  TV_REQUIRE(act_operand >= 0 && act_operand <= 2, "tv_gemm_f32_act: act_operand must be 0, 1 or 2");
+  if (act_operand != 0) {
+    TV_REQUIRE(act_scale && act_shift, "tv_gemm_f32_act: null scale / shift");
+    TV_REQUIRE(act_operand != 1 || !trans_a, "tv_gemm_f32_act: the A prologue needs trans_a = 0");
+    TV_REQUIRE(act_operand != 2 || !trans_b, "tv_gemm_f32_act: the B prologue needs trans_b = 0");
+    TV_REQUIRE((((uintptr_t)act_scale | (uintptr_t)act_shift) & 15) == 0,
+               "tv_gemm_f32_act: scale / shift must be 16-byte aligned");
+    TV_REQUIRE(act_slope >= 0.f && act_slope <= 1.f, "tv_gemm_f32_act: slope must be in [0, 1]");
+  }
   // 16-B loads need aligned rows and a contiguous extent that is a multiple of 4
   g.a_vec = (lda % 4 == 0) && (((uintptr_t)a & 15) == 0) && ((trans_a ? m : k) % 4 == 0);
   g.b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0) && ((trans_b ? k : n) % 4 == 0);
@@ -518,6 +653,23 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
   const dim3 grid((unsigned)nwg), block(256);
   const int variant = (trans_a != 0 ? 8 : 0) | (trans_b == 0 ? 4 : 0) | (g.a_vec ? 2 : 0) |
                       (g.b_vec ? 1 : 0);
+#define TV_GEMM_ACT_CASE(V, AK, BK_, AV, BV, ACT)                                               \
+  case V: hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, AV, BV, ACT>), grid, block, 0, s, g); break;
+  if (act_operand == 1) {          // A row-major
+    switch (variant) {
+      TV_GEMM_ACT_CASE(0, false, false, false, false, 1) TV_GEMM_ACT_CASE(1, false, false, false, true, 1)
+      TV_GEMM_ACT_CASE(2, false, false, true, false, 1)  TV_GEMM_ACT_CASE(3, false, false, true, true, 1)
+      TV_GEMM_ACT_CASE(4, false, true, false, false, 1)  TV_GEMM_ACT_CASE(5, false, true, false, true, 1)
+      TV_GEMM_ACT_CASE(6, false, true, true, false, 1)   TV_GEMM_ACT_CASE(7, false, true, true, true, 1)
+    }
+  } else if (act_operand == 2) {   // B k-major
+    switch (variant) {
+      TV_GEMM_ACT_CASE(4, false, true, false, false, 2)  TV_GEMM_ACT_CASE(5, false, true, false, true, 2)
+      TV_GEMM_ACT_CASE(6, false, true, true, false, 2)   TV_GEMM_ACT_CASE(7, false, true, true, true, 2)
+      TV_GEMM_ACT_CASE(12, true, true, false, false, 2)  TV_GEMM_ACT_CASE(13, true, true, false, true, 2)
+      TV_GEMM_ACT_CASE(14, true, true, true, false, 2)   TV_GEMM_ACT_CASE(15, true, true, true, true, 2)
+    }
+  } else
 #define TV_GEMM_CASE(V, AK, BK_, AV, BV)                                                        \
   case V: hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, AV, BV>), grid, block, 0, s, g); break;
   switch (variant) {
@@ -531,6 +683,7 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
     TV_GEMM_CASE(14, true, true, true, false)   TV_GEMM_CASE(15, true, true, true, true)
   }
 #undef TV_GEMM_CASE
+#undef TV_GEMM_ACT_CASE
   TV_LAUNCH_CHECK("tv_gemm_f32");
   if (g.splits > 1) {
     int64_t blocks = tv_cdiv(m * n, 256);
@@ -544,4 +697,24 @@ extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64
     TV_LAUNCH_CHECK("tv_gemm_f32(tail reduce)");
   }
   return TV_OK;
+}
+}  // namespace
+
+extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k,
+                           const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                           int64_t ldc, const float *bias, const float *row_scale,
+                           int accumulate, void *workspace, int64_t workspace_bytes,
+                           void *stream) {
+  return run_gemm(trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, row_scale, accumulate,
+                  0, nullptr, nullptr, 0.f, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tv_gemm_f32_act(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k,
+                               const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                               int64_t ldc, const float *bias, const float *row_scale,
+                               int accumulate, int act_operand, const float *act_scale,
+                               const float *act_shift, float act_slope, void *workspace,
+                               int64_t workspace_bytes, void *stream) {
+  return run_gemm(trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, row_scale, accumulate,
+                  act_operand, act_scale, act_shift, act_slope, workspace, workspace_bytes, stream);
 }

@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int64_t C, int64_t nbl
                                                           double count, float eps, float momentum,
                                                           float *mean, float *rstd,
                                                           float *running_mean,
-                                                          float *running_var) {
+                                                          float *running_var,
+                                                          const float *gamma, const float *beta,
+                                                          float *scale, float *shift) {
   const int64_t col = (int64_t)blockIdx.x * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
   double tot[2];
   tv_slot_sums<2>(partial, nblk, 2 * C, C, col, col < C, tot);
@@ -42,7 +44,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int64_t C, int64_t nbl
   double var = tot[1] / count - m * m;
   if (var < 0.0) var = 0.0;
   mean[col] = (float)m;
-  rstd[col] = (float)(1.0 / sqrt(var + (double)eps));
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  rstd[col] = rs;
+  if (scale) {          // y = x*scale + shift, the folded form the GEMM prologue applies
+    const float sc = gamma[col] * rs;
+    scale[col] = sc;
+    shift[col] = beta[col] - (float)m * sc;
+  }
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
     running_mean[col] = (float)((1.0 - momentum) * (double)running_mean[col] + momentum * m);
@@ -208,8 +216,26 @@ extern "C" int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, 
              "tv_bn_finalize: running_mean and running_var go together");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(tv_slot_grid(cols)), dim3(256), 0,
                      (hipStream_t)stream, cols, nblk, partial, (double)count, eps, momentum, mean,
-                     rstd, running_mean, running_var);
+                     rstd, running_mean, running_var, (const float *)nullptr,
+                     (const float *)nullptr, (float *)nullptr, (float *)nullptr);
   TV_LAUNCH_CHECK("tv_bn_finalize");
+  return TV_OK;
+}
+
+extern "C" int tv_bn_finalize_coeffs(int64_t cols, int64_t nblk, const float *partial,
+                                     int64_t count, float eps, float momentum, float *mean,
+                                     float *rstd, float *running_mean, float *running_var,
+                                     const float *gamma, const float *beta, float *scale,
+                                     float *shift, void *stream) {
+  TV_REQUIRE(cols >= 1 && nblk >= 1 && count >= 1, "tv_bn_finalize_coeffs: bad sizes");
+  TV_REQUIRE(partial && mean && rstd && gamma && beta && scale && shift,
+             "tv_bn_finalize_coeffs: null pointer");
+  TV_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+             "tv_bn_finalize_coeffs: running_mean and running_var go together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(tv_slot_grid(cols)), dim3(256), 0,
+                     (hipStream_t)stream, cols, nblk, partial, (double)count, eps, momentum, mean,
+                     rstd, running_mean, running_var, gamma, beta, scale, shift);
+  TV_LAUNCH_CHECK("tv_bn_finalize_coeffs");
   return TV_OK;
 }
 

@@ -43,6 +43,9 @@ COMPACT_LATENCY_DECODER = os.environ.get('TRACEVAE_COMPACT_LATDEC', '1') != '0'
 LRELU_SLOPE = 0.01
 # the RealNVP prior as one HIP kernel per direction (0: the PyTorch formulation, for A/B runs)
 FUSED_PRIOR_FLOW = os.environ.get('TRACEVAE_FUSED_FLOW', '1') != '0'
+# training: BatchNorm + LeakyReLU between two GAT layers applied inside the next layer's GEMMs
+# instead of as a pass of its own (0: materialise every activation, for A/B runs)
+FUSED_BN_LINEAR = os.environ.get('TRACEVAE_FUSED_BN_LINEAR', '1') != '0'
 
 
 # ---------------------------------------------------------------------------------------
@@ -188,6 +191,22 @@ class _GATParams(nn.Module):
         nn.init.xavier_normal_(self.attn_r, gain=gain)
 
 
+class _DeferredBN(object):
+    """Output of a GAT layer whose BatchNorm(batch statistics) + LeakyReLU has not been applied:
+    the next layer's fc applies it to its operand inside the GEMM (`ops.bn_lrelu_linear`)."""
+    __slots__ = ['x', 'stats', 'bn', 'row_weight', 'count']
+
+    def __init__(self, x, stats, bn, row_weight, count):
+        self.x, self.stats, self.bn, self.row_weight, self.count = x, stats, bn, row_weight, count
+
+    def linear(self, weight):
+        bn = self.bn
+        bn.num_batches_tracked += 1
+        return ops.bn_lrelu_linear(self.x, bn.weight, bn.bias, weight, bn.running_mean,
+                                   bn.running_var, bn.eps, bn.momentum, LRELU_SLOPE, self.stats,
+                                   self.row_weight, self.count)
+
+
 class GATConvAgg(nn.Module):
     """GATConv -> concat heads -> BatchNorm -> LeakyReLU (gnn_layers.py:112-157)."""
 
@@ -197,12 +216,13 @@ class GATConvAgg(nn.Module):
         self.gnn = _GATParams(input_dim, output_dim, num_heads)
         self.normalization = BatchNorm(self.output_dim) if use_batch_norm else None
 
-    def forward(self, graph: ops.DeviceGraph, h: torch.Tensor, n_rep: int = 1,
-                row_weight=None, count=None) -> torch.Tensor:
+    def forward(self, graph: ops.DeviceGraph, h, n_rep: int = 1, row_weight=None, count=None,
+                defer: bool = False):
         """`row_weight` / `count`: rows that stand for several identical rows of the batch
-        (compact latency decoder); only the BatchNorm statistics see the difference."""
+        (compact latency decoder); only the BatchNorm statistics see the difference.
+        `defer`: in training mode return a `_DeferredBN` for the next GAT layer to consume."""
         g = self.gnn
-        ft = ops.linear(h, g.fc.weight)
+        ft = h.linear(g.fc.weight) if isinstance(h, _DeferredBN) else ops.linear(h, g.fc.weight)
         bn = self.normalization
         if bn is None:
             out, _ = ops.gat_conv(ft, g.attn_l, g.attn_r, g.bias, graph, n_rep)
@@ -210,6 +230,8 @@ class GATConvAgg(nn.Module):
         if bn.training:
             out, stats = ops.gat_conv(ft, g.attn_l, g.attn_r, g.bias, graph, n_rep, want_stats=True,
                                       stats_row_weight=row_weight)
+            if defer and FUSED_BN_LINEAR:
+                return _DeferredBN(out, stats, bn, row_weight, count)
             return bn.forward_lrelu(out, stats, row_weight, count)
         if not torch.is_grad_enabled():
             # eval + no_grad: BatchNorm(running stats) + LeakyReLU ride in the aggregate epilogue
@@ -266,8 +288,9 @@ class GNNSequential(nn.Module):
         self.gnn = nn.ModuleList(list(layers) + [tail])
 
     def _run(self, graph, h, n_rep, tail_arg, row_weight, count):
-        for layer in list(self.gnn)[:-1]:
-            h = layer(graph, h, n_rep, row_weight, count)
+        layers = list(self.gnn)[:-1]
+        for i, layer in enumerate(layers):
+            h = layer(graph, h, n_rep, row_weight, count, defer=i + 1 < len(layers))
         tail = self.gnn[len(self.gnn) - 1]
         if isinstance(tail, _Pooling):
             return tail(tail_arg, h)

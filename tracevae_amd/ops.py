@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 from . import hip
 
 __all__ = [
-    'DeviceGraph', 'TIMER', 'gemm', 'linear', 'matmul_nn', 'rowdot', 'colsum', 'gat_conv', 'bn_lrelu',
+    'DeviceGraph', 'TIMER', 'gemm', 'linear', 'matmul_nn', 'rowdot', 'colsum', 'gat_conv', 'bn_lrelu', 'bn_lrelu_linear',
     'graph_sum', 'segment_mean', 'embedding', 'latdec_input', 'latdec_rows', 'adj_bernoulli_ll',
     'categorical_ll', 'normal_reparam', 'normal_ll', 'realnvp_log_prob', 'realnvp_supported',
     'latency_ll', 'score_reduce',
@@ -117,8 +117,12 @@ class DeviceGraph(object):
 # ---------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
          bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
-         out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """C = row_scale * (op(a) @ op(b)) + bias on the fp32 MFMA kernel (`tv_gemm_f32`)."""
+         out: Optional[torch.Tensor] = None, accumulate: bool = False,
+         act: Optional[tuple] = None) -> torch.Tensor:
+    """C = row_scale * (op(a) @ op(b)) + bias on the fp32 MFMA kernel (`tv_gemm_f32`).
+    `act = (operand, scale, shift, slope)`: operand 1 (a, not transposed) or 2 (b, not
+    transposed) goes through lrelu(v * scale[f] + shift[f]) on its way into the kernel
+    (`tv_gemm_f32_act`)."""
     a, b = _check(a, 'a'), _check(b, 'b')
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     n, kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
@@ -134,9 +138,20 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
     wsb = hip.query('tv_gemm_f32_workspace_bytes', m, n, k)
     ws = _workspace(wsb, a.device)
     with TIMER.region('gemm_f32', 2.0 * m * n * k, (m, n, k, bool(trans_a), bool(trans_b))):
-        hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr(a), a.stride(0),
-                 hip.ptr(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
-                 hip.ptr(row_scale), int(accumulate), hip.ptr(ws), wsb)
+        if act is None:
+            hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr(a), a.stride(0),
+                     hip.ptr(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
+                     hip.ptr(row_scale), int(accumulate), hip.ptr(ws), wsb)
+        else:
+            operand, scale, shift, slope = act
+            feats = k if operand == 1 else n
+            if scale.numel() != feats or shift.numel() != feats:
+                raise ValueError(f'gemm: act scale / shift must have {feats} entries')
+            hip.call('tv_gemm_f32_act', int(trans_a), int(trans_b), m, n, k, hip.ptr(a),
+                     a.stride(0), hip.ptr(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
+                     hip.ptr(row_scale), int(accumulate), int(operand),
+                     hip.ptr(_check(scale, 'act scale')), hip.ptr(_check(shift, 'act shift')),
+                     float(slope), hip.ptr(ws), wsb)
     return c
 
 
@@ -381,6 +396,69 @@ class _BNLReLUTrain(Function):
                  hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), ctx.slope, hip.ptr(ctx.row_weight),
                  ctx.count, hip.ptr(dx), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), wsb)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class _BNLReLULinear(Function):
+    """ft = LeakyReLU(BatchNorm_train(x)) @ W^T without writing the activation: the normalised,
+    activated rows only exist inside the two GEMMs that consume them (forward product and
+    weight gradient, `tv_gemm_f32_act`).  Same arithmetic as `_BNLReLUTrain` + `_Linear` with
+    the affine folded (y = x*scale + shift)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, running_mean, running_var, eps, momentum, slope,
+                stats, row_weight=None, count=None):
+        x, weight = _check(x, 'x'), _check(weight, 'weight')
+        gamma, beta = _check(gamma, 'gamma'), _check(beta, 'beta')
+        rows, cols = x.shape
+        dev = x.device
+        count = rows if row_weight is None else int(count)
+        if count < 2:
+            raise ValueError('Expected more than 1 value per channel when training')
+        if stats is None or stats.numel() == 0:
+            stats = torch.empty([hip.query('tv_stat_blocks', rows), 2, cols], dtype=_f32, device=dev)
+            hip.call('tv_colstats', rows, cols, hip.ptr(x), hip.ptr(row_weight), hip.ptr(stats))
+        # mean, rstd, scale, shift; rows padded so that each starts 16-byte aligned
+        coeffs = torch.empty([4, (cols + 3) // 4 * 4], dtype=_f32, device=dev)
+        mean, rstd, scale, shift = (coeffs[i, :cols] for i in range(4))
+        hip.call('tv_bn_finalize_coeffs', cols, stats.shape[0], hip.ptr(stats), count, float(eps),
+                 float(momentum), hip.ptr(mean), hip.ptr(rstd), hip.ptr(running_mean),
+                 hip.ptr(running_var), hip.ptr(gamma), hip.ptr(beta), hip.ptr(scale),
+                 hip.ptr(shift))
+        ft = gemm(x, weight, False, True, act=(1, scale, shift, slope))
+        ctx.save_for_backward(x, coeffs, gamma, beta, weight)
+        ctx.slope = float(slope)
+        ctx.row_weight, ctx.count = row_weight, count
+        return ft
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dft):
+        x, coeffs, gamma, beta, weight = ctx.saved_tensors
+        rows, cols = x.shape
+        mean, rstd, scale, shift = (coeffs[i, :cols] for i in range(4))
+        dft = _check(dft, 'dft')
+        dx = dgamma = dbeta = dw = None
+        if ctx.needs_input_grad[3]:
+            dw = gemm(dft, x, True, False, act=(2, scale, shift, ctx.slope))
+        if any(ctx.needs_input_grad[:3]):
+            dy = gemm(dft, weight, False, False)
+            dx = torch.empty_like(x)
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+            wsb = hip.query('tv_bn_lrelu_bwd_workspace_bytes', rows, cols)
+            ws = _workspace(wsb, x.device)
+            hip.call('tv_bn_lrelu_bwd', rows, cols, hip.ptr(x), hip.ptr(dy), hip.ptr(mean),
+                     hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), ctx.slope,
+                     hip.ptr(ctx.row_weight), ctx.count, hip.ptr(dx), hip.ptr(dgamma),
+                     hip.ptr(dbeta), hip.ptr(ws), wsb)
+        return (dx, dgamma, dbeta, dw) + (None,) * 8
+
+
+def bn_lrelu_linear(x, gamma, beta, weight, running_mean, running_var, eps: float,
+                    momentum: float = 0.1, slope: float = 0.01, stats=None, row_weight=None,
+                    count=None):
+    """`linear(bn_lrelu(x, training=True), weight)` as one operator (see `_BNLReLULinear`)."""
+    return _BNLReLULinear.apply(x, gamma, beta, weight, running_mean, running_var, eps, momentum,
+                                slope, stats, row_weight, count)
 
 
 class _AffineLReLU(Function):
