@@ -135,12 +135,37 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
     for (int c = 0; c < CH; ++c) ssum[c] = ssq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
+  // A row costs a chain of dependent loads: indptr -> indices -> scores -> neighbour rows.  The
+  // first two links are taken off the chain by looking ahead: (p0, deg) of the row after next
+  // and the neighbour index of the next row are loaded while this row is being gathered.
+  int64_t p0_b = 0, s_b = 0, p0_a = 0;
+  int deg_b = 0, deg_a = 0;
+  if (wave < a.rows) {
+    const int64_t v = wave % a.rows_per_rep;
+    p0_b = a.indptr[v];
+    deg_b = (int)(a.indptr[v + 1] - p0_b);
+    s_b = (lane < deg_b) ? a.indices[p0_b + lane] : 0;
+  }
+  if (wave + nwaves < a.rows) {
+    const int64_t v = (wave + nwaves) % a.rows_per_rep;
+    p0_a = a.indptr[v];
+    deg_a = (int)(a.indptr[v + 1] - p0_a);
+  }
   for (int64_t r = wave; r < a.rows; r += nwaves) {
     const int64_t rep = r / a.rows_per_rep;
     const int64_t v = r - rep * a.rows_per_rep;
     const int64_t base = rep * a.rows_per_rep;
-    const int64_t p0 = a.indptr[v];
-    const int deg = (int)(a.indptr[v + 1] - p0);
+    const int64_t p0 = p0_b;
+    const int deg = deg_b;
+    const int64_t s_rel = s_b;
+    p0_b = p0_a;
+    deg_b = deg_a;
+    if (r + nwaves < a.rows) s_b = (lane < deg_b) ? a.indices[p0_b + lane] : 0;
+    if (r + 2 * nwaves < a.rows) {
+      const int64_t v2 = (r + 2 * nwaves) % a.rows_per_rep;
+      p0_a = a.indptr[v2];
+      deg_a = (int)(a.indptr[v2 + 1] - p0_a);
+    }
     float erv[HT];
 #pragma unroll
     for (int h = 0; h < HT; ++h) erv[h] = (h < H) ? a.er[r * H + h] : 0.f;
@@ -152,7 +177,17 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
       // the usual case (a span has few neighbours): one edge per lane, the index and the score
       // are loaded once and the whole softmax stays in registers
       const bool live = lane < deg;
-      const int64_t s = live ? base + a.indices[p0 + lane] : 0;
+      const int64_t s = live ? base + s_rel : 0;
+      // the first neighbour's row does not depend on the softmax: fetch it under the scores
+      float4 first[CH];
+      {
+        const float4 *srow0 = reinterpret_cast<const float4 *>(a.ft + __shfl(s, 0, 64) * HF);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          first[c] = (q < c4) ? srow0[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
       float e[HT], al[HT];
 #pragma unroll
       for (int h = 0; h < HT; ++h)
@@ -165,7 +200,14 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
         al[h] = ex / den;
         if (a.alpha && live && h < H) a.alpha[(rep * a.num_edges + p0 + lane) * H + h] = al[h];
       }
-      for (int jj = 0; jj < deg; ++jj) {
+      if (deg > 0) {
+        float aj[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) aj[h] = __shfl(al[h], 0, 64);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = f4_fma(sel_head<HT>(aj, hc[c]), first[c], acc[c]);
+      }
+      for (int jj = 1; jj < deg; ++jj) {
         const int64_t sj = __shfl(s, jj, 64);
         float aj[HT];
 #pragma unroll

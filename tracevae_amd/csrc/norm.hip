@@ -171,6 +171,79 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
+// the same two stages on float4 columns (C % 4 == 0, 16-byte aligned operands): a thread owns
+// four columns, keeps their coefficients in registers and walks rows with 16-byte accesses.
+// Row order and arithmetic per element are those of the scalar kernels (bit-identical results).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(
+    int64_t rows, int64_t C, const float *__restrict__ x, const float *__restrict__ dy,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+    float *__restrict__ partial) {
+  const int64_t c4 = C >> 2;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nblk = gridDim.y, by = blockIdx.y;
+  if (q >= c4) return;
+  const float4 m = reinterpret_cast<const float4 *>(mean)[q];
+  const float4 rs = reinterpret_cast<const float4 *>(rstd)[q];
+  const float4 g = reinterpret_cast<const float4 *>(gamma)[q];
+  const float4 b = reinterpret_cast<const float4 *>(beta)[q];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const float mm[4] = {m.x, m.y, m.z, m.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
+  const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll 4
+  for (int64_t r = by; r < rows; r += nblk) {
+    const float4 xv = reinterpret_cast<const float4 *>(x)[r * c4 + q];
+    const float4 dv = reinterpret_cast<const float4 *>(dy)[r * c4 + q];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xs[j] - mm[j]) * rr[j];
+      const float pre = fmaf(gg[j], xh, bb[j]);
+      const float dyl = ds[j] * (pre > 0.f ? 1.f : slope);
+      s1[j] += dyl;
+      s2[j] = fmaf(dyl, xh, s2[j]);
+    }
+  }
+  reinterpret_cast<float4 *>(partial + (by * 2 + 0) * C)[q] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+  reinterpret_cast<float4 *>(partial + (by * 2 + 1) * C)[q] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(
+    int64_t rows, int64_t C, const float *__restrict__ x, const float *__restrict__ dy,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+    const float *__restrict__ sums, const float *__restrict__ row_weight, float inv_n,
+    float *__restrict__ dx) {
+  const int64_t c4 = C >> 2;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= c4) return;
+  const float4 m = reinterpret_cast<const float4 *>(mean)[q];
+  const float4 rs = reinterpret_cast<const float4 *>(rstd)[q];
+  const float4 g = reinterpret_cast<const float4 *>(gamma)[q];
+  const float4 b = reinterpret_cast<const float4 *>(beta)[q];
+  const float4 t1 = reinterpret_cast<const float4 *>(sums)[q];
+  const float4 t2 = reinterpret_cast<const float4 *>(sums + C)[q];
+  const float mm[4] = {m.x, m.y, m.z, m.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
+  const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+  const float u1[4] = {t1.x, t1.y, t1.z, t1.w}, u2[4] = {t2.x, t2.y, t2.z, t2.w};
+#pragma unroll 4
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float4 xv = reinterpret_cast<const float4 *>(x)[r * c4 + q];
+    const float4 dv = reinterpret_cast<const float4 *>(dy)[r * c4 + q];
+    const float wn = row_weight ? row_weight[r] * inv_n : inv_n;
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xs[j] - mm[j]) * rr[j];
+      const float pre = fmaf(gg[j], xh, bb[j]);
+      const float dyl = ds[j] * (pre > 0.f ? 1.f : slope);
+      o[j] = gg[j] * rr[j] * (dyl - u1[j] * wn - xh * u2[j] * wn);
+    }
+    reinterpret_cast<float4 *>(dx)[r * c4 + q] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void affine_lrelu_bwd_kernel(
     int64_t rows, int64_t C, const float *__restrict__ x, const float *__restrict__ dy,
     const float *__restrict__ scale, const float *__restrict__ shift, float slope,
@@ -308,15 +381,30 @@ extern "C" int tv_bn_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const
   const int64_t nblk = tv_stat_blocks_host(rows);
   float *partial = (float *)workspace;
   float *sums = partial + nblk * 2 * cols;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)tv_cdiv(cols, 256), (unsigned)nblk),
-                     dim3(256), 0, s, rows, cols, x, dy, mean, rstd, gamma, beta, slope, partial);
+  // `sums` sits behind nblk*2*cols floats of a 16-byte aligned workspace: aligned when cols % 4 == 0
+  const bool vec = vec_ok(cols, x, dy) && vec_ok(cols, mean, rstd) && vec_ok(cols, gamma, beta) &&
+                   vec_ok(cols, dx, workspace);
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3((unsigned)tv_cdiv(cols / 4, 256), (unsigned)nblk),
+                       dim3(256), 0, s, rows, cols, x, dy, mean, rstd, gamma, beta, slope, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)tv_cdiv(cols, 256), (unsigned)nblk),
+                       dim3(256), 0, s, rows, cols, x, dy, mean, rstd, gamma, beta, slope, partial);
   TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(reduce)");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tv_slot_grid(cols)), dim3(256), 0, s,
                      cols, nblk, partial, sums, dgamma, dbeta);
   TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(finalize)");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, s, rows,
-                     cols, x, dy, mean, rstd, gamma, beta, slope, sums, row_weight,
-                     (float)(1.0 / (double)count), dx);
+  if (vec) {
+    const int64_t cblocks = tv_cdiv(cols / 4, 256);
+    int64_t rblocks = tv_cdiv(4096, cblocks);
+    if (rblocks > rows) rblocks = rows;
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((unsigned)cblocks, (unsigned)rblocks), dim3(256),
+                       0, s, rows, cols, x, dy, mean, rstd, gamma, beta, slope, sums, row_weight,
+                       (float)(1.0 / (double)count), dx);
+  } else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, s, rows,
+                       cols, x, dy, mean, rstd, gamma, beta, slope, sums, row_weight,
+                       (float)(1.0 / (double)count), dx);
   TV_LAUNCH_CHECK("tv_bn_lrelu_bwd(apply)");
   return TV_OK;
 }
