@@ -11,6 +11,8 @@
 //
 // HBM-bound.  Algorithmic bytes, forward, per destination row with d in-edges:
 //   4*HF*d (ft gathers) + 4*HF (out) + 8*H*(d+1) (scores) + 8*d (indices) + 4*H*d (alpha).
+#include <type_traits>
+
 #include "tv_common.h"
 #include "tv_slots.h"
 
@@ -207,7 +209,32 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
 #pragma unroll
         for (int c = 0; c < CH; ++c) acc[c] = f4_fma(sel_head<HT>(aj, hc[c]), first[c], acc[c]);
       }
-      for (int jj = 1; jj < deg; ++jj) {
+      // two neighbour rows in flight per trip
+      int jj = 1;
+      for (; jj + 1 < deg; jj += 2) {
+        const int64_t sj0 = __shfl(s, jj, 64), sj1 = __shfl(s, jj + 1, 64);
+        float aj0[HT], aj1[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+          aj0[h] = __shfl(al[h], jj, 64);
+          aj1[h] = __shfl(al[h], jj + 1, 64);
+        }
+        const float4 *srow0 = reinterpret_cast<const float4 *>(a.ft + sj0 * HF);
+        const float4 *srow1 = reinterpret_cast<const float4 *>(a.ft + sj1 * HF);
+        float4 x0[CH], x1[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          x0[c] = (q < c4) ? srow0[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          x1[c] = (q < c4) ? srow1[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          acc[c] = f4_fma(sel_head<HT>(aj0, hc[c]), x0[c], acc[c]);
+          acc[c] = f4_fma(sel_head<HT>(aj1, hc[c]), x1[c], acc[c]);
+        }
+      }
+      if (jj < deg) {
         const int64_t sj = __shfl(s, jj, 64);
         float aj[HT];
 #pragma unroll
@@ -328,6 +355,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
 // ------------------------------------------------------------------------------------
 template <int CH, int HT>
 __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
+  extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -337,6 +365,12 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
   int hc[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) hc[c] = ((lane + 64 * c) * 4) / F;
+
+  // dbias = column sums of dout: this kernel holds every dout row once, so the sum rides here
+  // (the node pass, which is short of registers, keeps only the two attention gradients)
+  float4 pb[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int64_t r = wave; r < a.rows; r += nwaves) {
     const int64_t rep = r / a.rows_per_rep;
@@ -352,6 +386,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
     for (int c = 0; c < CH; ++c) {
       const int q = lane + 64 * c;
       d[c] = (q < c4) ? drow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[c] = f4_add(pb[c], d[c]);
     }
 
     // pass 1: g_j for every in-edge (kept by lane j; spilled to dpre when deg > 64),
@@ -369,29 +404,47 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
       float gj[HT];
 #pragma unroll
       for (int h = 0; h < HT; ++h) gj[h] = 0.f;
-      for (int jj = 0; jj < cnt; ++jj) {
-        const int64_t sj = __shfl(s, jj, 64);
-        const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * HF);
-        float part[HT];
+      // two neighbour rows (and their wave reductions) in flight per trip (four measured slower:
+      // the extra registers cost more than the third and fourth load in flight gain)
+      auto edges = [&](auto nconst, int jj) {
+        constexpr int U = decltype(nconst)::value;
+        float4 x[U][CH];
 #pragma unroll
-        for (int h = 0; h < HT; ++h) part[h] = 0.f;
+        for (int u = 0; u < U; ++u) {
+          const float4 *srow = reinterpret_cast<const float4 *>(a.ft + __shfl(s, jj + u, 64) * HF);
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int q = lane + 64 * c;
-          if (q < c4) {
-            const float dp = f4_dot(d[c], srow[q]);
+          for (int c = 0; c < CH; ++c) {
+            const int q = lane + 64 * c;
+            x[u][c] = (q < c4) ? srow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        float part[U][HT];
 #pragma unroll
-            for (int h = 0; h < HT; ++h) part[h] += (hc[c] == h) ? dp : 0.f;
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int h = 0; h < HT; ++h) part[u][h] = 0.f;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const float dp = f4_dot(d[c], x[u][c]);
+#pragma unroll
+            for (int h = 0; h < HT; ++h) part[u][h] += (hc[c] == h) ? dp : 0.f;
           }
         }
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
           if (h < H) {
-            const float tot = tv_wave_sum(part[h]);
-            if (lane == jj) gj[h] = tot;
+            float tot[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) tot[u] = tv_wave_sum(part[u][h]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (lane == jj + u) gj[h] = tot[u];
           }
         }
-      }
+      };
+      int jj = 0;
+      for (; jj + 2 <= cnt; jj += 2) edges(std::integral_constant<int, 2>(), jj);
+      if (jj < cnt) edges(std::integral_constant<int, 1>(), jj);
       if (j < deg) {
 #pragma unroll
         for (int h = 0; h < HT; ++h)
@@ -433,6 +486,11 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
       }
     }
   }
+
+  float4 vb[1][CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) vb[0][c] = pb[c];
+  block_col_reduce<1, CH>(lds, vb, c4, a.partial + ((int64_t)blockIdx.x * 3 + 2) * HF);
 }
 
 // ------------------------------------------------------------------------------------
@@ -456,9 +514,9 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kerne
 #pragma unroll
   for (int c = 0; c < CH; ++c) hc[c] = ((lane + 64 * c) * 4) / F;
 
-  float4 pal[CH], par[CH], pb[CH];
+  float4 pal[CH], par[CH];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) pal[c] = par[c] = pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < CH; ++c) pal[c] = par[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int64_t r = wave; r < a.rows; r += nwaves) {
     const int64_t rep = r / a.rows_per_rep;
@@ -494,7 +552,32 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kerne
 #pragma unroll
       for (int h = 0; h < HT; ++h) del[h] += dp[h];
       const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
-      for (int jj = 0; jj < cnt; ++jj) {
+      // two neighbour rows in flight per trip
+      int jj = 0;
+      for (; jj + 1 < cnt; jj += 2) {
+        const int64_t wj0 = __shfl(w, jj, 64), wj1 = __shfl(w, jj + 1, 64);
+        float aj0[HT], aj1[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+          aj0[h] = __shfl(al[h], jj, 64);
+          aj1[h] = __shfl(al[h], jj + 1, 64);
+        }
+        const float4 *wrow0 = reinterpret_cast<const float4 *>(a.dout + wj0 * HF);
+        const float4 *wrow1 = reinterpret_cast<const float4 *>(a.dout + wj1 * HF);
+        float4 x0[CH], x1[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          x0[c] = (q < c4) ? wrow0[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          x1[c] = (q < c4) ? wrow1[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          acc[c] = f4_fma(sel_head<HT>(aj0, hc[c]), x0[c], acc[c]);
+          acc[c] = f4_fma(sel_head<HT>(aj1, hc[c]), x1[c], acc[c]);
+        }
+      }
+      if (jj < cnt) {
         const int64_t wj = __shfl(w, jj, 64);
         float aj[HT];
 #pragma unroll
@@ -515,7 +598,6 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kerne
     }
 
     const float4 *frow = reinterpret_cast<const float4 *>(a.ft + r * HF);
-    const float4 *drow = reinterpret_cast<const float4 *>(a.dout + r * HF);
     float4 *orow = reinterpret_cast<float4 *>(a.dft + r * HF);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -528,15 +610,14 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kerne
         const float4 f = frow[q];
         pal[c] = f4_fma(dl, f, pal[c]);
         par[c] = f4_fma(dr, f, par[c]);
-        pb[c] = f4_add(pb[c], drow[q]);
       }
     }
   }
 
-  float4 v[3][CH];
+  float4 v[2][CH];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) { v[0][c] = pal[c]; v[1][c] = par[c]; v[2][c] = pb[c]; }
-  block_col_reduce<3, CH>(lds, v, c4, a.partial + (int64_t)blockIdx.x * 3 * HF);
+  for (int c = 0; c < CH; ++c) { v[0][c] = pal[c]; v[1][c] = par[c]; }
+  block_col_reduce<2, CH>(lds, v, c4, a.partial + (int64_t)blockIdx.x * 3 * HF);
 }
 
 // out[s*C + c] = sum_b partial[b][s][c] in workgroup order (float64 accumulation)
@@ -698,15 +779,15 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   hipStream_t s = (hipStream_t)stream;
   const bool big = a.c4 > 256;
   {
-    int64_t blocks = tv_cdiv(rows, TV_STAT_WAVES);
-    if (blocks > tv_gat_max_blocks()) blocks = tv_gat_max_blocks();
-    const dim3 grid((unsigned)blocks), block(64 * TV_STAT_WAVES);
-    TV_GAT_LAUNCH(gat_bwd_edge_kernel, grid, block, 0, s, a);
+    // same grid as the node pass: both write their column partials into slot blockIdx.x
+    const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
+    const size_t ldsb = sizeof(float) * HF;
+    TV_GAT_LAUNCH(gat_bwd_edge_kernel, grid, block, ldsb, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(edge)");
   }
   {
     const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
-    const size_t ldsb = sizeof(float) * 3 * HF;
+    const size_t ldsb = sizeof(float) * 2 * HF;
     TV_GAT_LAUNCH(gat_bwd_node_kernel, grid, block, ldsb, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(node)");
   }
