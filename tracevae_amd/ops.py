@@ -325,9 +325,9 @@ class _GATConv(Function):
                         g.num_edges)
         ws = _workspace(wsb, dev)
         # algorithmic bytes: edge pass (dout row + ft per in-edge) + node pass (dout per
-        # in-edge, ft + dout rows read, dft written)
+        # in-edge, ft row read, dft written)
         hf = heads * feats
-        work = 4.0 * hf * (2 * g.num_edges + 4 * g.num_rows)
+        work = 4.0 * hf * (2 * g.num_edges + 3 * g.num_rows)
         with TIMER.region('gat_aggregate_bwd', work):
             hip.call('tv_gat_aggregate_bwd', g.num_rows, 1, heads, feats, g.num_edges,
                      hip.ptr(g.indptr), hip.ptr(g.indices), hip.ptr(g.rev), hip.ptr(ft),
