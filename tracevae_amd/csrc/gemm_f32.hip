@@ -52,6 +52,7 @@ struct GemmArgs {
   float *tail_slabs;
   int accumulate;
   int a_vec, b_vec;          // 16-byte loads allowed for the operand (host-side dispatch)
+  int c_vec;                 // 16-byte stores allowed for the output (ldc, N, base all % 4)
   // operand prologue (tv_gemm_f32_act): v -> lrelu(v * act_scale[f] + act_shift[f]) on the way
   // into LDS, f = the operand's feature index (k for a row-major A, n for a k-major B)
   const float *act_scale, *act_shift;
@@ -432,6 +433,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   float *out = split ? (g.slabs + (int64_t)sp * g.M * g.N) : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
   const bool plain = split || (!g.row_scale && !g.accumulate);
+#ifndef TV_GEMM_DIRECT_EPILOGUE
+  if (plain && g.c_vec && m0 + BM <= g.M) {
+    // all 128 rows of the tile exist and rows can be written 16 bytes per lane: the wave
+    // transposes its 64x64 block through LDS (the tile buffers are free now) and stores whole
+    // 256-byte row segments - 16 store instructions per lane instead of 64 scattered dwords.
+    // Row stride 72 floats: the two 32-lane halves of an accumulator register (rows r, r+4)
+    // land 32 banks apart.
+    constexpr int ES = 72;
+    static_assert(4 * 64 * ES <= 4 * TILE_FLOATS, "epilogue staging fits the tile buffers");
+    __syncthreads();                                // every wave is done with the last k-tile
+    float *ws = smem + wave * (64 * ES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ws[(i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * ES + j * 32 + xl] = acc[i][j][r];
+    const int c = (lane & 15) * 4;
+    const int64_t col = n0 + wn * 64 + c;
+    if (col < g.N) {                                // N % 4 == 0: the four columns exist together
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!split && g.bias) bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
+      float *o = out + (m0 + wm * 64 + (lane >> 4)) * ldo + col;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(&ws[(q * 4 + (lane >> 4)) * ES + c]);
+        *reinterpret_cast<float4 *>(o + (int64_t)q * 4 * ldo) =
+            make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+      }
+    }
+    return;
+  }
+#endif
   if (plain && m0 + BM <= g.M) {
     // all 128 rows of the tile exist: stores are only predicated on the column of the lane
     float *o = out + (m0 + wm * 64 + 4 * kh) * ldo + n0 + wn * 64 + xl;
@@ -636,6 +671,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   // 16-B loads need aligned rows and a contiguous extent that is a multiple of 4
   g.a_vec = (lda % 4 == 0) && (((uintptr_t)a & 15) == 0) && ((trans_a ? m : k) % 4 == 0);
   g.b_vec = (ldb % 4 == 0) && (((uintptr_t)b & 15) == 0) && ((trans_b ? k : n) % 4 == 0);
+  g.c_vec = (ldc % 4 == 0) && (((uintptr_t)c & 15) == 0) && (n % 4 == 0);
   if (plan.workspace_bytes > 0) {
     const int64_t need = plan.workspace_bytes;
     if (!workspace || workspace_bytes < need) {
@@ -643,7 +679,12 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
                    (long long)workspace_bytes);
       return TV_ERR_WORKSPACE;
     }
-    if (g.splits > 1) g.slabs = (float *)workspace; else g.tail_slabs = (float *)workspace;
+    if (g.splits > 1) {
+      g.slabs = (float *)workspace;      // the kernel's output is then a slab: [M, N] rows
+      g.c_vec = (n % 4 == 0) && (((uintptr_t)workspace & 15) == 0);
+    } else {
+      g.tail_slabs = (float *)workspace;
+    }
   }
   hipStream_t s = (hipStream_t)stream;
   const int64_t tiles = g.tiles_m * g.tiles_n;
