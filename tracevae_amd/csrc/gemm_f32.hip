@@ -618,9 +618,15 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
 
 int64_t choose_splits(int64_t m, int64_t n, int64_t k) {
   const int64_t tiles = tv_cdiv(m, BM) * tv_cdiv(n, BN);
-  if (tiles >= 256 || k < 8 * BK) return 1;
+  if (tiles >= 256 || k < 4 * BK) return 1;
   int64_t s = tv_cdiv(512, tiles);
-  const int64_t kmax = k / (4 * BK);  // at least 4 k-tiles per split
+  // a workgroup alone on its CU pays the full memory latency per k-tile, so few-tile problems
+  // are split deep: at least TV_GEMM_MIN_SPLIT_TILES (default 2) k-tiles per split
+  static const int64_t min_tiles = [] {
+    const char *e = getenv("TV_GEMM_MIN_SPLIT_TILES");
+    return (e && atoll(e) > 0) ? atoll(e) : 2ll;
+  }();
+  const int64_t kmax = k / (min_tiles * BK);
   if (s > kmax) s = kmax;
   if (s > 64) s = 64;
   if (s < 1) s = 1;
