@@ -292,17 +292,18 @@ def test_graph_sum_segment_mean_embedding(device):
             got.backward(_dev(g, device))
             assert rel_err(got, ref) < TOL
             assert rel_err(xd.grad, xr.grad) < TOL and rel_err(wd.grad, wr.grad) < TOL
-    # readout
+    # readout (16-byte column path and the scalar one)
     rows = db.enc.num_rows
-    x = _rand(rows, 1000, seed=5)
-    xr = x.clone().requires_grad_(True)
-    ref = avg_pooling(xr, ob['node_offsets'])
-    g = _rand(*ref.shape, seed=6)
-    ref.backward(g)
-    xd = _dev(x, device).requires_grad_(True)
-    got = ops.segment_mean(xd, db.node_offsets, db.graph_id)
-    got.backward(_dev(g, device))
-    assert rel_err(got, ref) < TOL and rel_err(xd.grad, xr.grad) < TOL
+    for width in (1000, 250, 37):
+        x = _rand(rows, width, seed=5)
+        xr = x.clone().requires_grad_(True)
+        ref = avg_pooling(xr, ob['node_offsets'])
+        g = _rand(*ref.shape, seed=6)
+        ref.backward(g)
+        xd = _dev(x, device).requires_grad_(True)
+        got = ops.segment_mean(xd, db.node_offsets, db.graph_id)
+        got.backward(_dev(g, device))
+        assert rel_err(got, ref) < TOL and rel_err(xd.grad, xr.grad) < TOL
     # embedding gather + per-operation segmented sum
     w = _rand(40, 40, seed=7)
     wr = w.clone().requires_grad_(True)
