@@ -27,7 +27,29 @@ __global__ __launch_bounds__(256) void graph_sum_vec_kernel(
       float4 acc[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int64_t p = p0; p < p1; ++p) {
+      // two neighbour rows in flight per trip (the rows are still added in edge order)
+      int64_t p = p0;
+      for (; p + 2 <= p1; p += 2) {
+        const int64_t u0 = indices[p], u1 = indices[p + 1];
+        const float ns0 = scale_src ? deg_norm(indptr, u0) : 1.0f;
+        const float ns1 = scale_src ? deg_norm(indptr, u1) : 1.0f;
+        const float4 *urow0 = reinterpret_cast<const float4 *>(x) + (base + u0) * c4;
+        const float4 *urow1 = reinterpret_cast<const float4 *>(x) + (base + u1) * c4;
+        float4 t0[4], t1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t q = q0 + lane + 64 * c;
+          t0[c] = (q < c4) ? urow0[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          t1[c] = (q < c4) ? urow1[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          // DGL scales the source features first, then sums (appendix A2)
+          acc[c].x += t0[c].x * ns0; acc[c].y += t0[c].y * ns0; acc[c].z += t0[c].z * ns0; acc[c].w += t0[c].w * ns0;
+          acc[c].x += t1[c].x * ns1; acc[c].y += t1[c].y * ns1; acc[c].z += t1[c].z * ns1; acc[c].w += t1[c].w * ns1;
+        }
+      }
+      if (p < p1) {
         const int64_t u = indices[p];
         const float ns = scale_src ? deg_norm(indptr, u) : 1.0f;
         const float4 *urow = reinterpret_cast<const float4 *>(x) + (base + u) * c4;
@@ -36,7 +58,6 @@ __global__ __launch_bounds__(256) void graph_sum_vec_kernel(
           const int64_t q = q0 + lane + 64 * c;
           if (q < c4) {
             const float4 t = urow[q];
-            // DGL scales the source features first, then sums (appendix A2)
             acc[c].x += t.x * ns; acc[c].y += t.y * ns; acc[c].z += t.z * ns; acc[c].w += t.w * ns;
           }
         }
