@@ -136,6 +136,21 @@ int tv_gemm_f32_act(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, c
                     const float *act_scale, const float *act_shift, float act_slope,
                     void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Linear layers with one small side, min(in_features, out_features) <= 16 - the z / z2 mean and
+ * log-std heads (1000 -> 10) and the first layers fed by z (10 -> 500 / 250):
+ * model/struct_vae.py:139-180, model/latency_vae.py:181-203.  y = x W^T + bias with W
+ * [out_features, in_features] as torch / tensorkit Linear stores it.  At 512 rows these products
+ * are far too small for the 128x128 MFMA tiles.  Backward: dx (nullable) and
+ * dwb = [dW (out*in) | dbias (out)] in one buffer; fixed-order two-stage reduction over rows. */
+int tv_skinny_linear_fwd(int64_t rows, int64_t in_features, int64_t out_features, const float *x,
+                         const float *w, const float *bias /* nullable */, float *out,
+                         void *stream);
+int64_t tv_skinny_linear_bwd_workspace_bytes(int64_t rows, int64_t in_features,
+                                             int64_t out_features);
+int tv_skinny_linear_bwd(int64_t rows, int64_t in_features, int64_t out_features, const float *x,
+                         const float *w, const float *dout, float *dx /* nullable */, float *dwb,
+                         void *workspace, int64_t workspace_bytes, void *stream);
+
 /* skinny right-hand side (N <= 8): out[r,j] = row_scale[r] * sum_k x[r,k] w[k,j]  (w is [K,N])
  * Replaces the 1000->2 GraphConv matmul of the latency decoder (model/latency_vae.py:221-229,
  * DGL multiplies by W before aggregating when in > out). */

@@ -80,6 +80,37 @@ def test_linear_autograd(device):
     assert rel_err(bd.grad, br.grad) < TOL
 
 
+@pytest.mark.parametrize('lead,k,n,bias', [((512,), 1000, 10, True), ((3, 40), 250, 10, True),
+                                          ((700,), 64, 16, False), ((5,), 77, 1, True),
+                                          ((512,), 10, 500, True), ((3, 40), 10, 1000, False),
+                                          ((33,), 16, 250, True), ((9,), 1, 64, True)])
+def test_skinny_linear_autograd(device, lead, k, n, bias):
+    """Linear layers with one small side (<= 16 inputs or outputs) take the skinny kernels
+    instead of the MFMA GEMM."""
+    from tracevae_amd import ops
+    x, w = _rand(*lead, k, seed=1), _rand(n, k, seed=2)
+    b = _rand(n, seed=3) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    ref = F.linear(xr, wr, br)
+    g = _rand(*ref.shape, seed=4)
+    ref.backward(g)
+    xd, wd = _dev(x, device).requires_grad_(True), _dev(w, device).requires_grad_(True)
+    bd = _dev(b, device).requires_grad_(True) if bias else None
+    got = ops.linear(xd, wd, bd)
+    assert got.grad_fn.__class__.__name__.startswith('_SkinnyLinear')
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL
+    assert rel_err(xd.grad, xr.grad) < TOL and rel_err(wd.grad, wr.grad) < TOL
+    if bias:
+        assert rel_err(bd.grad, br.grad) < TOL
+    # frozen input: no dx
+    xd2 = _dev(x, device)
+    wd2 = _dev(w, device).requires_grad_(True)
+    ops.linear(xd2, wd2, None).backward(_dev(g, device))
+    assert rel_err(wd2.grad, wr.grad) < TOL
+
+
 def test_matmul_nn_and_rowdot_autograd(device):
     from tracevae_amd import ops
     x, w, b = _rand(301, 64, seed=1), _rand(64, 131, seed=2), _rand(131, seed=3)

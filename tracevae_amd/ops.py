@@ -195,7 +195,47 @@ class _Linear(Function):
         return dx, dw, db
 
 
+class _SkinnyLinear(Function):
+    """`_Linear` with one small side, min(in, out) <= 16 (`tv_skinny_linear_*`): the z / z2
+    heads (1000 -> 10) and the first layers fed by z (10 -> 500)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = _check(x.reshape(-1, x.shape[-1]), 'x')
+        weight = _check(weight, 'weight')
+        rows, k = x2.shape
+        n = weight.shape[0]
+        y = torch.empty([rows, n], dtype=_f32, device=x2.device)
+        hip.call('tv_skinny_linear_fwd', rows, k, n, hip.ptr(x2), hip.ptr(weight),
+                 hip.ptr(None if bias is None else _check(bias, 'bias')), hip.ptr(y))
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.x_shape = x.shape
+        return y.reshape(x.shape[:-1] + (n,))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        rows, k = x2.shape
+        n = weight.shape[0]
+        dy2 = _check(dy.reshape(-1, n), 'dy')
+        if rows == 0:
+            return (torch.zeros(ctx.x_shape, dtype=_f32, device=x2.device), torch.zeros_like(weight),
+                    torch.zeros([n], dtype=_f32, device=x2.device) if ctx.has_bias else None)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dwb = torch.empty([n * k + n], dtype=_f32, device=x2.device)
+        wsb = hip.query('tv_skinny_linear_bwd_workspace_bytes', rows, k, n)
+        ws = _workspace(wsb, x2.device)
+        hip.call('tv_skinny_linear_bwd', rows, k, n, hip.ptr(x2), hip.ptr(weight), hip.ptr(dy2),
+                 hip.ptr(dx), hip.ptr(dwb), hip.ptr(ws), wsb)
+        return (None if dx is None else dx.reshape(ctx.x_shape), dwb[:n * k].view(n, k),
+                dwb[n * k:] if ctx.has_bias else None)
+
+
 def linear(x, weight, bias=None):
+    if min(weight.shape) <= 16 and max(weight.shape) >= 64:
+        return _SkinnyLinear.apply(x, weight, bias)
     return _Linear.apply(x, weight, bias)
 
 
