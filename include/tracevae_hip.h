@@ -42,6 +42,8 @@ extern "C" {
 #define TV_BATCH_BAD_EDGE 2       /* an edge violates 0 <= u < v < n                        */
 #define TV_BATCH_MISSING_LATENCY_RANGE 4 /* operation without (mean,std): reference KeyError */
 #define TV_BATCH_BAD_NODE_TYPE 8  /* node_type outside [0, num_operations)                  */
+/* status bit written by tv_sampled_graph_count */
+#define TV_SAMPLED_BAD_ADJ 16     /* a sampled adjacency entry is neither 0 nor 1           */
 
 const char *tv_last_error(void);
 int tv_version(void);
@@ -99,6 +101,36 @@ int tv_batch_build(int64_t batch, int64_t max_node_count, int64_t total_nodes,
                    float *lat_row_weight, /* nullable, see above */
                    int32_t *status, /* device int32, OR-ed TV_BATCH_* bits; caller zeroes it */
                    void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * decoder graphs of traces SAMPLED from the prior (section 8f row 4)
+ *
+ * Replaces make_graph in TraceStructVAE.p (model/struct_vae.py:296-333: triu_to_dense +
+ * T.where + dgl.graph + dgl.add_reverse_edges + dgl.add_self_loop + the node_idx formula,
+ * then dgl.batch over the samples).  adj [G, M(M-1)/2] f32 holds 0/1 draws of the strict
+ * upper triangle, row-major (tensor_utils.py:60-67); any DAG, not only trees.
+ *
+ * Two calls, because the edge total is data dependent:
+ *   tv_sampled_graph_count -> indptr [G*M+1] (final values) and graph_edge_offsets [G+1];
+ *       the caller reads E = graph_edge_offsets[G] back and sizes the arrays below with it;
+ *   tv_sampled_graph_fill  -> src/dst [E] COO in DGL edge-id order, per graph
+ *       [u->v in row-major order ; the same reversed ; self x M], node ids g*M + local;
+ *       indices/eids [E] = stable sort by destination; rev [E] = CSC position of the
+ *       opposite edge; node_idx [G*M] = max(max_u(adj[u,v] * cumsum_v(adj[u,:])) - 1, 0).
+ * Both take the same workspace (tv_sampled_graph_workspace_bytes); fill must follow count on
+ * the same adjacency (a graph whose edge total no longer matches is left unwritten).
+ * ---------------------------------------------------------------------------------- */
+int64_t tv_sampled_graph_workspace_bytes(int64_t graphs, int64_t max_node_count);
+int tv_sampled_graph_count(int64_t graphs, int64_t max_node_count, const float *adj,
+                           int64_t *indptr, int64_t *graph_edge_offsets, void *ws,
+                           int64_t ws_bytes,
+                           int32_t *status, /* device int32, OR-ed TV_SAMPLED_*; caller zeroes */
+                           void *stream);
+int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int64_t num_edges,
+                          const float *adj, const int64_t *graph_edge_offsets,
+                          const int64_t *indptr, int64_t *src, int64_t *dst, int64_t *indices,
+                          int64_t *eids, int64_t *rev, int64_t *node_idx, void *ws,
+                          int64_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * dense layers: C[M,N] = row_scale[m] * (op(A)[M,K] . op(B)[K,N]) + bias[n]

@@ -7,6 +7,7 @@ Plain per-trace Python loops, like the reference; follows
 * `dense_triu_adj`/`dense_to_triu`  tensor_utils.py:79-89, 64-67
 * `pad_node_feature`              tensor_utils.py:92-114
 * decoder graph rebuild           model/struct_vae.py:335-362
+* graphs of sampled adjacencies   model/struct_vae.py:296-333, tensor_utils.py:70-76
 
 and the DGL graph semantics of SURVEY.md appendix A0: `dgl.graph` keeps COO order (edge
 id = position), `add_self_loop` / `add_reverse_edges` append, `dgl.batch` shifts node ids
@@ -19,7 +20,7 @@ import numpy as np
 
 __all__ = [
     'encoder_coo', 'decoder_coo', 'csc_from_coo', 'reverse_positions', 'dense_triu_adj',
-    'normalize_latency', 'build_batch',
+    'normalize_latency', 'build_batch', 'triu_to_dense', 'sampled_graphs',
 ]
 
 
@@ -146,3 +147,40 @@ def build_batch(node_offsets: np.ndarray, u: np.ndarray, v: np.ndarray,
         node_count=node_count, node_type=node_type[:n_total].astype(np.int64),
         latency=latency, graph_id=graph_id,
     )
+
+
+def triu_to_dense(triu: np.ndarray, max_node_count: int, pad_value=0) -> np.ndarray:
+    """tensor_utils.py:70-76: the row-major strict upper triangle back into an M x M matrix."""
+    m = max_node_count
+    out = np.full([m, m], pad_value, dtype=triu.dtype)
+    out[np.triu(np.ones([m, m], dtype=bool), 1)] = triu
+    return out
+
+
+def sampled_graphs(adj_triu: np.ndarray, max_node_count: int) -> Dict[str, np.ndarray]:
+    """`make_graph` of TraceStructVAE.p (model/struct_vae.py:298-316) for each sampled
+    adjacency, then `dgl.batch` (:320-331): edges `where(adj)` in row-major order, the reversed
+    list appended (`add_reverse_edges`), M self loops appended (`add_self_loop`); node ids and
+    edge ids shifted graph by graph; `node_idx = max(max_u(adj * cumsum(adj, -1)) - 1, 0)`."""
+    m = max_node_count
+    srcs: List[np.ndarray] = []
+    dsts: List[np.ndarray] = []
+    node_idx = []
+    offsets = [0]
+    for g, row in enumerate(np.asarray(adj_triu)):
+        adj = triu_to_dense(row, m)
+        u, v = np.nonzero(adj)
+        loop = np.arange(m, dtype=np.int64)
+        srcs.append(np.concatenate([u, v, loop]).astype(np.int64) + g * m)
+        dsts.append(np.concatenate([v, u, loop]).astype(np.int64) + g * m)
+        offsets.append(offsets[-1] + len(srcs[-1]))
+        ranks = (adj * np.cumsum(adj, axis=-1)).max(axis=-2).astype(np.int64) - 1
+        node_idx.append(np.maximum(ranks, 0))
+    n_graphs = len(offsets) - 1
+    src = np.concatenate(srcs) if srcs else np.zeros([0], dtype=np.int64)
+    dst = np.concatenate(dsts) if dsts else np.zeros([0], dtype=np.int64)
+    indptr, indices, eids = csc_from_coo(src, dst, n_graphs * m)
+    return dict(src=src, dst=dst, indptr=indptr, indices=indices, eids=eids,
+                rev=reverse_positions(indptr, indices),
+                node_idx=np.concatenate(node_idx) if node_idx else np.zeros([0], dtype=np.int64),
+                graph_edge_offsets=np.asarray(offsets, dtype=np.int64))

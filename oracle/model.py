@@ -223,6 +223,36 @@ class OracleTraceVAE(object):
         base = (-0.5 * LOG_2PI - 0.5 * x ** 2).sum(-1)
         return (base + logdet).reshape(lead)
 
+    def _flow_sample(self, P, name, eps):
+        """z = flow(eps) of FlowDistribution(UnitNormal, flow.invert()) (struct_vae.py:251-254):
+        the levels of `_flow_log_prob` undone in reverse order."""
+        cfg = self.cfg.struct.realnvp
+        zdim = eps.shape[-1]
+        n1 = zdim // 2
+        lead = eps.shape[:-1]
+        x = eps.reshape(-1, zdim)
+        for lvl in reversed(range(cfg.flow_levels)):
+            a, c, d = (f'{name}.original_flow.flows.{3 * lvl + k}' for k in range(3))
+            w = P[d + '.kernel']
+            x = torch.linalg.solve(w.double(), x.double().t()).t().to(x.dtype)
+            y1, y2 = x[:, :n1], x[:, n1:]
+            hdn = y1
+            for j in range(cfg.coupling_hidden_layer_count):
+                s = f'{c}.shift_and_pre_scale.shared.{j}'
+                hdn = F.leaky_relu(hdn @ P[s + '.weight_store.value'].t() + P[s + '.bias_store.value'], 0.01)
+            b0, b1 = (f'{c}.shift_and_pre_scale.branches.{k}.0' for k in range(2))
+            shift = hdn @ P[b0 + '.weight_store.value'].t() + P[b0 + '.bias_store.value']
+            pre = hdn @ P[b1 + '.weight_store.value'].t() + P[b1 + '.bias_store.value']
+            if cfg.coupling_layer_scale == 'sigmoid':
+                log_scale = F.logsigmoid(pre + 2.0)
+            elif cfg.coupling_layer_scale == 'exp':
+                log_scale = pre
+            else:
+                raise NotImplementedError(cfg.coupling_layer_scale)
+            x = torch.cat([y1, y2 * torch.exp(-log_scale) - shift], dim=-1)
+            x = x * torch.exp(-P[a + '.pre_scale']) - P[a + '.bias']
+        return x.reshape(lead + (zdim,))
+
     # ------------------------------------------------------------------------- q / p
     def q(self, P, buf, batch, eps_z, eps_z2, training, no_latency=False):
         """TraceVAE.q: returns z, z2 and log q(z), log q(z2).  `training` is a bool or a

@@ -1,0 +1,195 @@
+"""Prior sampling on the GPU: `tv_sampled_graph_*` bit-exact
+against the NumPy restatement of the reference's `make_graph` (model/struct_vae.py:296-333),
+and `TraceVAE.p(n_z=...)` without an observed graph against the CPU oracle fed with the same
+noise and the same discrete outcomes (1e-4 relative, fp32 against the float64 oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_config, oracle_state, rel_err
+from oracle.batching import sampled_graphs
+
+pytestmark = pytest.mark.gpu
+PATH_TOL = 1e-4
+
+
+def _random_adj(graphs, m, density, seed):
+    rng = np.random.default_rng(seed)
+    t = m * (m - 1) // 2
+    if density is None:                       # a different density per graph, 0 and 1 included
+        dens = np.linspace(0.0, 1.0, graphs)[:, None]
+    else:
+        dens = density
+    return (rng.random((graphs, t)) < dens).astype(np.float32)
+
+
+@pytest.mark.parametrize('graphs,m,density', [(1, 2, 0.5), (3, 2, None), (7, 5, None), (64, 32, 0.1),
+                                              (33, 100, 0.02), (5, 100, None), (300, 17, 0.3),
+                                              (2, 300, 0.01), (0, 10, 0.5)])
+def test_sampled_graph_build_is_bit_exact(device, graphs, m, density):
+    from tracevae_amd.batch import build_sampled_graphs
+    adj = _random_adj(graphs, m, density, seed=graphs * 1000 + m)
+    ref = sampled_graphs(adj, m)
+    g, node_idx = build_sampled_graphs(torch.from_numpy(adj).to(device), m)
+    assert g.num_rows == graphs * m and g.num_edges == len(ref['src'])
+    for name in ('indptr', 'indices', 'eids', 'rev', 'src', 'dst'):
+        assert np.array_equal(getattr(g, name).cpu().numpy(), ref[name]), name
+    assert np.array_equal(node_idx.cpu().numpy(), ref['node_idx'])
+
+
+def test_sampled_graph_refuses_bad_input(device):
+    from tracevae_amd import hip
+    from tracevae_amd.batch import build_sampled_graphs
+    with pytest.raises(ValueError, match='neither 0 nor 1'):
+        build_sampled_graphs(torch.full([2, 10], 0.5, device=device), 5)
+    with pytest.raises(ValueError, match='adj must be'):
+        build_sampled_graphs(torch.zeros([2, 9], device=device), 5)
+    with pytest.raises(hip.HipLibraryError):
+        build_sampled_graphs(torch.zeros([2, 10]), 5)
+    # the C-ABI itself: a workspace that is too small, an impossible edge total
+    adj = torch.zeros([2, 10], device=device)
+    out = torch.zeros([64], dtype=torch.int64, device=device)
+    st = torch.zeros([1], dtype=torch.int32, device=device)
+    p = hip.ptr
+    with pytest.raises(hip.HipLibraryError, match='workspace'):
+        hip.call('tv_sampled_graph_count', 2, 5, p(adj), p(out), p(out), p(out), 8, p(st))
+    with pytest.raises(hip.HipLibraryError, match='impossible'):
+        hip.call('tv_sampled_graph_fill', 2, 5, 3, p(adj), p(out), p(out), p(out), p(out), p(out),
+                 p(out), p(out), p(out), p(out), 512)
+
+
+def _model(device, V, M, width, layers, seed=0, extra=()):
+    from tracevae_amd.model import TraceVAE
+    torch.manual_seed(seed)
+    cfg = make_config(width=width, layers=layers, extra=extra)
+    vae = TraceVAE(cfg.model, V, max_node_count=M)
+    with torch.no_grad():
+        for name, buf in vae.named_buffers():
+            if name.endswith('running_mean'):
+                buf.normal_(0, 0.1)
+            elif name.endswith('running_var'):
+                buf.uniform_(0.5, 1.5)
+        for name, p in vae.named_parameters():
+            if name.endswith('pre_scale') or (name.endswith('.bias') and 'flows' in name):
+                p.normal_(0, 0.1)
+            if 'branches' in name and name.endswith('weight_store.value'):
+                p.normal_(0, 0.05)
+    for m in vae.modules():
+        if hasattr(m, 'initialized'):
+            m.initialized = True
+    P, buf, _ = oracle_state(vae, torch.float64)
+    vae.to(device).eval()
+    return cfg, vae, P, buf
+
+
+@pytest.mark.parametrize('use_flow,dims', [(True, (60, 16, 16, 2, 9)), (False, (60, 16, 16, 2, 9)),
+                                           # BASELINE configs[1] dims
+                                           (True, (1001, 100, None, None, 6))])
+def test_prior_sample_matches_oracle(device, use_flow, dims):
+    from oracle.model import OracleTraceVAE
+    V, M, width, layers, n = dims
+    extra = () if use_flow else ('--model.struct.decoder.use_prior_flow=false',)
+    cfg, vae, P, buf = _model(device, V, M, width, layers, seed=4, extra=extra)
+    gen = torch.Generator().manual_seed(11)
+    eps = {'z': torch.randn(n, 1, 10, generator=gen), 'z2': torch.randn(n, 1, 10, generator=gen),
+           'latency': torch.randn(n, M, 1, generator=gen)}
+    std_limit = torch.rand(V, generator=gen) * 0.5 + 0.05
+    with torch.no_grad():
+        net = vae.p(n_z=n, eps=eps, std_limit=std_limit.to(device))
+
+    # shapes of the reference: the sample axis first, one "batch" entry per sample
+    T = M * (M - 1) // 2
+    assert tuple(net['z'].tensor.shape) == (n, 1, 10)
+    assert tuple(net['node_count'].tensor.shape) == (n, 1)
+    assert tuple(net['adj'].tensor.shape) == (n, 1, T)
+    assert tuple(net['node_type'].tensor.shape) == (n, 1, M)
+    assert tuple(net['z2'].tensor.shape) == (n, 1, 10)
+    assert tuple(net['latency'].tensor.shape) == (n, 1, M, 1)
+    assert list(net) == ['z', 'node_count', 'adj', 'node_type', 'z2', 'latency']
+    adj = net['adj'].tensor.reshape(n, T).cpu()
+    node_count = net['node_count'].tensor.reshape(n).cpu()
+    node_type = net['node_type'].tensor.reshape(n, M).cpu()
+    latency = net['latency'].tensor.reshape(n, M, 1).cpu()
+    assert set(adj.unique().tolist()) <= {0.0, 1.0}
+    assert int(node_count.min()) >= 0 and int(node_count.max()) <= M
+    assert int(node_type.min()) >= 0 and int(node_type.max()) < V
+    # masked sample: nothing beyond the drawn node count
+    slot = torch.arange(M)[None, :, None]
+    assert float(latency[slot.expand_as(latency) >= node_count[:, None, None]].abs().sum()) == 0.0
+
+    # the oracle on the same noise and the same discrete outcomes, samples as a batch
+    orc = OracleTraceVAE(cfg.model, V, M, dtype=torch.float64)
+    with torch.no_grad():
+        z_ref = orc._flow_sample(P, 'struct_vae.pz_flow', eps['z'].double().reshape(n, 10)) \
+            if use_flow else eps["z"].double().reshape(n, 10)
+    assert rel_err(net['z'].tensor.reshape(n, 10), z_ref) < PATH_TOL
+    graphs = sampled_graphs(adj.numpy(), M)
+    ob = dict(dec_src=graphs['src'], dec_dst=graphs['dst'], node_count=node_count.numpy(),
+              adj=adj.numpy(), node_type_pad=node_type.numpy(), latency_pad=latency.numpy())
+    z = net['z'].tensor.reshape(n, 10).cpu().double()
+    z2 = net['z2'].tensor.reshape(n, 10).cpu().double()
+    with torch.no_grad():
+        ref = orc.p(P, buf, ob, z, z2, training=False, std_limit=std_limit.double())
+    for name, key in (('z', 'log_p_z'), ('node_count', 'log_p_node_count'), ('adj', 'log_p_adj'),
+                      ('node_type', 'log_p_node_type'), ('z2', 'log_p_z2'),
+                      ('latency', 'log_p_latency')):
+        assert rel_err(net[name].log_prob().reshape(n), ref[key]) < PATH_TOL, name
+    assert rel_err(net['adj'].distribution.logits.reshape(n, T), ref['edge_logits']) < PATH_TOL
+    assert rel_err(net['node_type'].distribution.logits.reshape(n, M, V),
+                   ref['node_type_logits']) < PATH_TOL
+    base = net['latency'].distribution.base_distribution
+    assert rel_err(base.mean.reshape(n, M, 1), ref['latency_mean']) < PATH_TOL
+    assert rel_err(base.std.reshape(n, M, 1), torch.exp(ref['latency_logstd'])) < PATH_TOL
+    # z2 and the latencies are the reparameterised draws of the oracle's parameters
+    lat_ref = ref['latency_mean'] + torch.exp(ref['latency_logstd']) * eps['latency'].double()
+    lat_ref = lat_ref * (slot < node_count[:, None, None])
+    assert rel_err(latency, lat_ref) < PATH_TOL
+
+    # pinned discrete outcomes reproduce the net; fresh ones differ somewhere
+    draws = {'node_count': node_count, 'adj': adj, 'node_type': node_type}
+    with torch.no_grad():
+        again = vae.p(n_z=n, eps=eps, draws=draws, std_limit=std_limit.to(device))
+    for name in net:
+        assert torch.equal(again[name].tensor, net[name].tensor), name
+        assert torch.equal(again[name].log_prob(), net[name].log_prob()), name
+
+
+def test_prior_sample_without_a_sample_axis_and_without_latency(device):
+    cfg, vae, P, buf = _model(device, 60, 16, 16, 2, seed=1)
+    with torch.no_grad():
+        net = vae.p(no_latency=True)
+    assert tuple(net['z'].tensor.shape) == (1, 10)
+    assert tuple(net['adj'].tensor.shape) == (1, 120)
+    assert list(net) == ['z', 'node_count', 'adj', 'node_type']
+    assert net.meta['g'].num_rows == 16
+
+
+def test_do_evaluate_prior(device, tmp_path):
+    import json
+    from tracevae_amd.data import TraceGraphLatencyRangeFile
+    from tracevae_amd.evaluation import do_evaluate_prior
+    V, M = 60, 16
+    cfg, vae, P, buf = _model(device, V, M, 16, 2, seed=2)
+    lr = TraceGraphLatencyRangeFile(latency_data={k: {'mean': 5.0 + k, 'std': 1.5}
+                                                  for k in range(1, V)})
+    from tracevae_amd.data import TraceGraphIDManager
+    ids = TraceGraphIDManager.from_mappings({'': 0}, {f'op{k}' if k else '': k for k in range(V)})
+    torch.manual_seed(0)
+    out = tmp_path / 'prior.json'
+    res, kept = do_evaluate_prior(vae, ids, lr, n_samples=40, batch_size=16, eval_n_z=3,
+                                  nll_threshold=1e30, output_file=str(out),
+                                  latency_hist_out='x', rng=np.random.default_rng(0),
+                                  return_samples=True)
+    assert json.loads(out.read_text()) == res
+    assert 0.0 <= res['drop_rate'] <= 1.0
+    # 3 batches of 16 were drawn; what is not dropped is kept
+    assert len(kept) == round(48 * (1.0 - res['drop_rate']))
+    for g in kept:
+        assert 2 <= g.node_count <= M and g.node_count == g.root.count_nodes()
+        for _, node in g.iter_bfs():
+            ops_ = [c.operation_id for c in node.children]
+            assert ops_ == sorted(set(ops_)) and node.operation_id != 0
+    # everything is dropped when nothing may pass the threshold
+    res = do_evaluate_prior(vae, ids, lr, n_samples=16, batch_size=16, eval_n_z=2,
+                            nll_threshold=-1e30, rng=np.random.default_rng(0))
+    assert res['drop_rate'] == 1.0

@@ -26,7 +26,7 @@ from .data import (FlatTraces, TraceGraph, TraceGraphIDManager, TraceGraphLatenc
                    flatten_trace_graphs)
 from .ops import DeviceGraph
 
-__all__ = ['DeviceTraceStore', 'DeviceBatch', 'TraceGraphBatch']
+__all__ = ['DeviceTraceStore', 'DeviceBatch', 'TraceGraphBatch', 'build_sampled_graphs']
 
 _STATUS_TEXT = {
     1: 'a trace has more than MAX_NODE_COUNT nodes',
@@ -176,6 +176,40 @@ def build_device_batch(store: DeviceTraceStore, trace_ids: np.ndarray,
     if check and store.needs_status_check:
         out.check_status()
     return out
+
+
+def build_sampled_graphs(adj: torch.Tensor, max_node_count: int):
+    """Decoder graphs of SAMPLED adjacencies: `make_graph` + `dgl.batch` of
+    `TraceStructVAE.p` without an observed graph (model/struct_vae.py:296-333), on the GPU
+    (`tv_sampled_graph_count` / `tv_sampled_graph_fill`).
+
+    `adj` [G, M(M-1)/2] float32 with 0/1 entries.  Returns `(graph, node_idx)`: the batched
+    `DeviceGraph` (G*M nodes) and the `node_idx` node data [G*M].  One host read-back (the
+    edge total sizes the arrays), as the reference's `T.where` has per sample."""
+    m = int(max_node_count)
+    t = m * (m - 1) // 2
+    if adj.dim() != 2 or adj.shape[1] != t:
+        raise ValueError(f'adj must be [graphs, {t}] for MAX_NODE_COUNT={m}: got {tuple(adj.shape)}')
+    if not adj.is_cuda:
+        raise hip.HipLibraryError('build_sampled_graphs runs on the GPU only (no CPU fallback)')
+    adj = adj.to(torch.float32).contiguous()
+    dev, g = adj.device, int(adj.shape[0])
+    i64 = lambda n: torch.empty([n], dtype=torch.int64, device=dev)
+    indptr, offs = i64(g * m + 1), i64(g + 1)
+    ws_bytes = hip.query('tv_sampled_graph_workspace_bytes', g, m)
+    ws = torch.empty([max(ws_bytes, 8) // 8 + 1], dtype=torch.int64, device=dev)
+    status = torch.zeros([1], dtype=torch.int32, device=dev)
+    p = hip.ptr
+    hip.call('tv_sampled_graph_count', g, m, p(adj), p(indptr), p(offs), p(ws), ws_bytes,
+             p(status))
+    e, code = int(offs[-1].item()), int(status.item())
+    if code:
+        raise ValueError('a sampled adjacency entry is neither 0 nor 1')
+    src, dst, indices, eids, rev = (i64(e) for _ in range(5))
+    node_idx = i64(g * m)
+    hip.call('tv_sampled_graph_fill', g, m, e, p(adj), p(offs), p(indptr), p(src), p(dst),
+             p(indices), p(eids), p(rev), p(node_idx), p(ws), ws_bytes)
+    return DeviceGraph(indptr, indices, eids, rev, src, dst), node_idx
 
 
 class TraceGraphBatch(object):

@@ -71,6 +71,17 @@ class TraceGraphNode(_SlotState):
     scores: Optional[Any] = None
     anomaly: Optional[int] = None
 
+    @staticmethod
+    def new_sampled(node_id: int, operation_id: int, features: TraceGraphNodeFeatures,
+                    scores: Optional[TraceGraphNodeReconsScores] = None) -> 'TraceGraphNode':
+        """A node of a generated trace (trace_graph.py:86-100): no service, no spans."""
+        return TraceGraphNode(node_id=node_id, service_id=None, operation_id=operation_id,
+                              features=features, children=[], spans=None, scores=scores,
+                              anomaly=None)
+
+    def count_nodes(self) -> int:
+        return sum(1 for _ in self.iter_bfs())
+
     def iter_bfs(self, with_parent: bool = False) -> Iterator[tuple]:
         """Level-order walk.  Yields `(depth, node)` or, with `with_parent`,
         `(depth, index_among_siblings, node, parent)` (reference: trace_graph.py:102-137)."""
@@ -114,6 +125,12 @@ class TraceGraph(_SlotState):
     @staticmethod
     def default_version() -> int:
         return 0x2
+
+    @staticmethod
+    def new_sampled(root: TraceGraphNode, node_count: int, max_depth: int) -> 'TraceGraph':
+        """A generated trace (trace_graph.py:197-206)."""
+        return TraceGraph(version=TraceGraph.default_version(), trace_id=None, parent_id=None,
+                          root=root, node_count=node_count, max_depth=max_depth, data={})
 
     @property
     def edge_count(self) -> Optional[int]:

@@ -19,8 +19,8 @@ import torch.distributed as dist
 from .batch import TraceGraphBatch
 from .model import TraceVAE
 
-__all__ = ['eval_step', 'do_evaluate_nll', 'analyze_anomaly_nll', 'best_fscore',
-           'fscore_for_precision_and_recall', 'DeviceCollector']
+__all__ = ['eval_step', 'do_evaluate_nll', 'do_evaluate_prior', 'analyze_anomaly_nll',
+           'best_fscore', 'fscore_for_precision_and_recall', 'DeviceCollector']
 
 
 @torch.no_grad()
@@ -240,4 +240,73 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
                             anomaly_degree=nll_list / result['best_threshold_latency'])
     result['_nll_list'] = nll_list
     result['_label_list'] = label_list
+    return result
+
+
+@torch.no_grad()
+def do_evaluate_prior(vae: TraceVAE, id_manager, latency_range, n_samples: int, batch_size: int,
+                      eval_n_z: int, nll_threshold: Optional[float] = None,
+                      use_biased: bool = True, output_file: Optional[str] = None,
+                      latency_hist_out: Optional[str] = None, rng=None,
+                      return_samples: bool = False):
+    """Sample traces from the prior and report how many have to be dropped
+    (`do_evaluate_prior`, evaluation.py:319-395): per batch `vae.p(n_z=batch_size)` draws the
+    traces on the GPU, `p_net_to_trace_graphs` turns them into trees (malformed ones count
+    as dropped), the survivors are scored with the K-sample NLL and those at or above
+    `nll_threshold` are dropped as well.  Writes `{'drop_rate': ...}` as JSON / YAML.
+
+    Two deliberate differences: the reference chains `vae.p` WITHOUT `G=G`
+    (evaluation.py:369-370), so its "NLL of the generated trace" is in fact the importance
+    weight of yet another freshly drawn trace - here the generated traces are scored
+    themselves; and a generated trace of a single node is counted as dropped (the batching
+    kernel takes traces of two nodes and more).
+
+    `rng` feeds `p_net_to_trace_graphs`; with `return_samples` the kept traces are returned
+    next to the result dict.  `latency_hist_out` only switches the per-operation latency
+    collection on, as in the reference (which gathers the values and never writes them)."""
+    from .graph_utils import p_net_to_trace_graphs
+    if nll_threshold is None:
+        nll_threshold = math.inf
+    sample_count = drop_count = 0
+    latency_map: Dict[int, List[float]] = {}
+    kept = []
+    n_batches = (n_samples + batch_size - 1) // batch_size
+    for _ in range(n_batches):
+        p = vae.p(n_z=batch_size)
+        graphs = p_net_to_trace_graphs(
+            p, id_manager=id_manager, latency_range=latency_range,
+            discard_node_with_type_0=True, discard_node_with_unknown_latency_range=True,
+            discard_graph_with_error_node_count=True, rng=rng,
+            max_node_count=vae.max_node_count)
+        sample_count += len(graphs)
+        drop_count += sum(g is None for g in graphs)
+        # a single node is no trace for the encoder (graph_vectors needs an edge)
+        lone = [g for g in graphs if g is not None and g.node_count < 2]
+        drop_count += len(lone)
+        graphs = [g for g in graphs if g is not None and g.node_count >= 2]
+        if not graphs:
+            continue
+        G = TraceGraphBatch(id_manager=id_manager, latency_range=latency_range,
+                            trace_graphs=graphs)
+        G._max_node_count = vae.max_node_count
+        _, nll = eval_step(vae, G, eval_n_z, use_biased=use_biased, use_latency_biased=False)
+        for g, v in zip(graphs, nll.cpu().numpy()):
+            if v >= nll_threshold:
+                drop_count += 1
+                continue
+            kept.append(g)
+            if latency_hist_out is not None:
+                for _, nd in g.iter_bfs():
+                    latency_map.setdefault(int(nd.operation_id), []).append(
+                        float(nd.features.avg_latency))
+    result = {'drop_rate': float(drop_count / sample_count) if sample_count else 0.0}
+    if output_file is not None:
+        import json
+        import yaml
+        _, ext = os.path.splitext(output_file)
+        text = json.dumps(result) if ext == '.json' else yaml.safe_dump(result)
+        with open(output_file, 'w', encoding='utf-8') as f:
+            f.write(text)
+    if return_samples:
+        return result, kept
     return result

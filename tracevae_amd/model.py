@@ -28,8 +28,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import constants as C
-from . import ops
-from .batch import DeviceBatch, TraceGraphBatch
+from . import hip, ops
+from .batch import DeviceBatch, TraceGraphBatch, build_sampled_graphs
 from .bayes import BayesianNet, Distribution, StochasticTensor
 from .config import TraceLatencyVAEConfig, TraceStructVAEConfig, TraceVAEConfig
 
@@ -475,6 +475,33 @@ class InverseRealNVP(nn.Module):
             return ops.realnvp_log_prob(z, params, levels, hidden, LRELU_SLOPE)
         return self.log_prob_torch(z)
 
+    def sample(self, eps: torch.Tensor) -> torch.Tensor:
+        """z = flow(eps) of `FlowDistribution(UnitNormal, original_flow.invert())`
+        (struct_vae.py:251-254): the original flow run backwards, level by level.  A few
+        10-dimensional rows, off the hot path: PyTorch, the dense inverse in float64."""
+        lead = eps.shape[:-1]
+        x = eps.reshape(-1, eps.shape[-1])
+        for flow in reversed(list(self.original_flow.flows)):
+            if isinstance(flow, InvertibleDense):
+                inv = torch.linalg.inv(flow.kernel.double()).to(x.dtype)
+                x = x @ inv.t()
+            elif isinstance(flow, CouplingLayer):
+                y1, y2 = x[:, :flow.n1], x[:, flow.n1:]
+                shift, pre = flow.shift_and_pre_scale(y1)
+                if flow.scale_type == 'sigmoid':
+                    log_scale = F.logsigmoid(pre + 2.0)
+                elif flow.scale_type == 'exp':
+                    log_scale = pre
+                else:
+                    raise NotImplementedError(flow.scale_type)
+                x = torch.cat([y1, y2 * torch.exp(-log_scale) - shift], dim=-1)
+            else:
+                if not flow.initialized:
+                    raise RuntimeError('the prior flow has not been initialised: train or '
+                                       'load a model before sampling from it')
+                x = x * torch.exp(-flow.pre_scale) - flow.bias
+        return x.reshape(lead + (x.shape[-1],))
+
     def log_prob_torch(self, z: torch.Tensor) -> torch.Tensor:
         lead = z.shape[:-1]
         x = z.reshape(-1, z.shape[-1])
@@ -558,10 +585,10 @@ class TraceStructVAE(nn.Module):
           use_biased: bool = False):
         cfg, M = self.config, self.max_node_count
         dec = cfg.decoder
-        if batch is None or 'z' not in net.observed:
-            raise NotImplementedError(
-                'sampling traces from the prior (struct_vae.py:296-333) is outside the '
-                'accelerated path: p() needs the observed batch G and z from q()')
+        if batch is None:
+            return self._p_sampled(net, n_z, use_biased)
+        if 'z' not in net.observed:
+            raise ValueError('p(G=...) needs the observed z of q(): chain it as q.chain(p, G=G)')
         z = net.observed['z']
         lead = z.shape[:-1]
         n_rep = z.shape[0] if z.dim() == 3 else 1
@@ -615,6 +642,87 @@ class TraceStructVAE(nn.Module):
             batch.node_type_pad, Distribution('Categorical', logits=logits_v), lp.reshape(lead)))
 
 
+    def _p_sampled(self, net: BayesianNet, n_z: Optional[int], use_biased: bool):
+        """`p()` without an observed graph (struct_vae.py:243-333, 394-414): every variable
+        that is not in `net.observed` is drawn, the decoder graphs come from the drawn
+        adjacency (`tv_sampled_graph_*`).  Shapes follow the reference: z `[n_z, 1, Z]` (or
+        `[1, Z]`), node_count `lead`, adj `lead + [T]`, node_type `lead + [M]`."""
+        cfg, M = self.config, self.max_node_count
+        dec = cfg.decoder
+        obs = net.observed
+        dev = self.pG_node_embedding.weight_store.value.device
+        if dev.type != 'cuda':
+            raise hip.HipLibraryError('the model lives on the CPU: the accelerated path runs on '
+                                      'the GPU only (there is no CPU fallback)')
+
+        # z ~ p(z)
+        if 'z' in obs:
+            z = torch.as_tensor(obs['z'], dtype=torch.float32, device=dev)
+        else:
+            eps = _sample_eps(net, 'z', n_z, 1, cfg.z_dim, dev)
+            z = self.pz_flow.sample(eps) if dec.use_prior_flow else eps
+        z = z.contiguous()
+        if dec.use_prior_flow:
+            log_pz = self.pz_flow.log_prob(z)
+            pz = Distribution('FlowDistribution', base_distribution=Distribution('UnitNormal'))
+        else:
+            zero = torch.zeros_like(z)
+            log_pz = ops.normal_ll(z, zero, zero)
+            pz = Distribution('UnitNormal')
+        net.add_node('z', StochasticTensor(z, pz, log_pz, n_z))
+        lead = tuple(z.shape[:-1])
+        z2d = z.reshape(-1, z.shape[-1])
+        graphs = z2d.shape[0]
+
+        def draw(name, make):
+            if name in obs:
+                return torch.as_tensor(obs[name], device=dev)
+            given = (net.meta.get('draws') or {}).get(name)
+            return torch.as_tensor(given, device=dev) if given is not None else make()
+
+        # node_count ~ p(node_count | z)
+        nc_logits = self.pG_node_count_logits(z2d)
+        node_count = draw('node_count', lambda: torch.multinomial(
+            torch.softmax(nc_logits, dim=-1), 1)).reshape(graphs).to(torch.int64).contiguous()
+        lp = ops.categorical_ll(nc_logits, node_count, use_biased, float(M * M), 0.5)
+        nc_logits_v = nc_logits.reshape(lead + (M + 1,))
+        net.add_node('node_count', StochasticTensor(
+            node_count.reshape(lead),
+            Distribution('BiasedCategorical' if use_biased else 'Categorical', logits=nc_logits_v,
+                         probs=lambda: torch.softmax(nc_logits_v, dim=-1)),
+            lp.reshape(lead)))
+
+        # adj ~ p(adj | z)
+        h = self.pG_node_embedding(self.pG_graph_embedding(z2d))
+        h = h.reshape(-1, M, dec.latent_embedding_size)
+        iu = torch.triu_indices(M, M, 1, device=dev)
+        edge_logits = torch.matmul(h, h.transpose(-1, -2))[:, iu[0], iu[1]]
+        adj = draw('adj', lambda: torch.bernoulli(torch.sigmoid(edge_logits)))
+        adj = adj.reshape(graphs, -1).to(torch.float32).contiguous()
+        lp = ops.adj_bernoulli_ll(h, adj, 1, use_biased, float(M), 0.5)
+        edge_logits_v = edge_logits.reshape(lead + (-1,))
+        net.add_node('adj', StochasticTensor(
+            adj.reshape(lead + (-1,)),
+            Distribution('BiasedBernoulli' if use_biased else 'Bernoulli', logits=edge_logits_v,
+                         probs=lambda: torch.sigmoid(edge_logits_v)),
+            lp.reshape(lead)))
+
+        # the decoder graphs of the drawn adjacencies (make_graph, struct_vae.py:298-331)
+        graph, node_idx = build_sampled_graphs(adj, M)
+        net.meta['g'] = graph
+        net.meta['node_idx'] = node_idx
+
+        # node_type ~ p(node_type | e, adj)
+        logits = self.pG_node_type_logits(graph, h.reshape(-1, dec.latent_embedding_size), 1)
+        node_type = draw('node_type', lambda: torch.multinomial(
+            torch.softmax(logits, dim=-1), 1)).reshape(graphs, M).to(torch.int64).contiguous()
+        lp = ops.categorical_ll(logits, node_type.reshape(-1)).reshape(-1, M).sum(-1)
+        logits_v = logits.reshape(lead + (M, self.num_operations))
+        net.add_node('node_type', StochasticTensor(
+            node_type.reshape(lead + (M,)), Distribution('Categorical', logits=logits_v),
+            lp.reshape(lead)))
+
+
 class TraceLatencyVAE(nn.Module):
     def __init__(self, config: TraceLatencyVAEConfig, z_dim: int,
                  operation_embedding: OperationEmbedding, max_node_count: int):
@@ -657,14 +765,16 @@ class TraceLatencyVAE(nn.Module):
         _latent_node(net, 'z2', self.qz2_mean(h), self.qz2_logstd(h), enc.z2_logstd_min,
                      enc.z2_logstd_max, n_z)
 
-    def p(self, net: BayesianNet, batch: DeviceBatch, n_z: Optional[int] = None,
+    def p(self, net: BayesianNet, batch: Optional[DeviceBatch], n_z: Optional[int] = None,
           use_biased: bool = False, latency_logstd_min: Optional[float] = None,
           latency_log_prob_weight: bool = False, std_limit: Optional[torch.Tensor] = None):
         cfg, M = self.config, self.max_node_count
         dec = cfg.decoder
+        if batch is None:
+            return self._p_sampled(net, n_z, use_biased, latency_logstd_min,
+                                   latency_log_prob_weight, std_limit)
         if 'z2' not in net.observed:
-            raise NotImplementedError('p() without an observed z2 (prior sampling) is outside '
-                                      'the accelerated path')
+            raise ValueError('p(G=...) needs the observed z2 of q(): chain it as q.chain(p, G=G)')
         z2 = net.observed['z2']
         lead = z2.shape[:-1]
         n_rep = z2.shape[0] if z2.dim() == 3 else 1
@@ -754,6 +864,107 @@ class TraceLatencyVAE(nn.Module):
         net.add_node('latency', StochasticTensor(batch.latency_pad, dist, ll.reshape(lead)))
 
 
+    def _p_sampled(self, net: BayesianNet, n_z: Optional[int], use_biased: bool,
+                   latency_logstd_min: Optional[float], latency_log_prob_weight: bool,
+                   std_limit: Optional[torch.Tensor]):
+        """`p()` on the graphs `struct_vae.p` drew (latency_vae.py:272-444 with `g =
+        net.meta['g']`).  z2 is drawn ONCE per drawn z (shape `lead + [Z2]`): the reference
+        passes `n_samples=n_z` again on a distribution whose batch shape already carries the
+        n_z axis, which gives `[n_z, n_z, 1, Z2]` and no usable decoder input."""
+        cfg, M = self.config, self.max_node_count
+        dec = cfg.decoder
+        obs = net.observed
+        if not dec.operation_embedding_stop_grad:
+            raise NotImplementedError('operation_embedding_stop_grad=False is non-default')
+        z = net['z'].tensor
+        lead = tuple(z.shape[:-1])
+        dev = z.device
+        graphs = z.numel() // z.shape[-1]
+
+        # z2 ~ p(z2 | z)
+        if dec.condition_on_z:
+            hz = self.z2_given_z_hidden_layers(z.detach() if dec.z2_given_z_stop_grad else z)
+            pz2_mean = self.pz2_mean[0](hz)
+            pz2_logstd_raw = self.pz2_logstd[0](hz)
+        else:
+            pz2_mean = torch.zeros(lead + (cfg.z2_dim,), device=dev)
+            pz2_logstd_raw = torch.zeros_like(pz2_mean)
+        pz2_logstd = _clip(pz2_logstd_raw, dec.z2_logstd_min, dec.z2_logstd_max) \
+            if dec.condition_on_z else pz2_logstd_raw
+        if 'z2' in obs:
+            z2 = torch.as_tensor(obs['z2'], dtype=torch.float32, device=dev).contiguous()
+        else:
+            eps = (net.meta.get('eps') or {}).get('z2')
+            eps = torch.randn_like(pz2_mean) if eps is None else \
+                torch.as_tensor(eps, dtype=torch.float32, device=dev).reshape(pz2_mean.shape)
+            z2 = (pz2_mean + torch.exp(pz2_logstd) * eps).contiguous()
+        if dec.condition_on_z:
+            lp = ops.normal_ll(z2, pz2_mean.contiguous(), pz2_logstd_raw.contiguous(),
+                               dec.z2_logstd_min, dec.z2_logstd_max)
+            pz2 = Distribution('Normal', mean=pz2_mean, logstd=pz2_logstd)
+        else:
+            lp = ops.normal_ll(z2, pz2_mean, pz2_logstd_raw)
+            pz2 = Distribution('UnitNormal')
+        net.add_node('z2', StochasticTensor(z2, pz2, lp, n_z))
+
+        # node features on the drawn graphs
+        node_type = net['node_type'].tensor.reshape(graphs, M).contiguous()
+        node_count = net['node_count'].tensor.reshape(graphs).contiguous()
+        h = ops.latdec_input(z2.reshape(-1, z2.shape[-1]), self.operation_embedding.weight.detach(),
+                             node_type, 1)
+        feats = self.pG_node_features(net.meta['g'], h, 1).contiguous()
+        self.last_compact = False
+
+        if latency_logstd_min is not None:
+            if dec.latency_logstd_min is not None:
+                latency_logstd_min = max(latency_logstd_min, dec.latency_logstd_min)
+        else:
+            latency_logstd_min = dec.latency_logstd_min
+        if self.training:
+            mode, thr, alpha = 'safe', dec.safe_normal_std_threshold, 1.0
+        elif use_biased and dec.use_biased_latency:
+            mode = 'anomaly' if dec.use_anomaly_detection_normal else 'biased'
+            thr, alpha = dec.biased_normal_std_threshold, float(M)
+        else:
+            mode, thr, alpha = 'normal', 0.0, 1.0
+        if std_limit is not None:
+            std_limit = torch.as_tensor(std_limit, dtype=torch.float32, device=dev).contiguous()
+
+        # latency ~ Normal(mean, std), masked to the drawn node_count (distributions.py:80-103)
+        shape4 = lead + (M, C.LATENCY_DIM)
+        mean = feats[:, :1].reshape(graphs, M, 1)
+        if 'latency' in obs:
+            x = torch.as_tensor(obs['latency'], dtype=torch.float32, device=dev)
+            x = x.reshape(graphs, M, 1).contiguous()
+        else:
+            logstd = feats[:, 1:2].reshape(graphs, M, 1)
+            if latency_logstd_min is not None:
+                logstd = logstd.clamp(min=latency_logstd_min)
+            if std_limit is not None:
+                logstd = torch.minimum(
+                    logstd, torch.log(std_limit[node_type].clamp(min=1e-7)).unsqueeze(-1))
+            eps = (net.meta.get('eps') or {}).get('latency')
+            eps = torch.randn_like(mean) if eps is None else \
+                torch.as_tensor(eps, dtype=torch.float32, device=dev).reshape(mean.shape)
+            x = mean + torch.exp(logstd) * eps
+            if dec.use_latency_mask:
+                slot = torch.arange(M, device=dev)[None, :, None]
+                x = x * (slot < node_count[:, None, None]).to(x.dtype)
+            x = x.contiguous()
+        ll, std = ops.latency_ll(
+            feats, x, node_count, node_type, 1, mode=mode, std_threshold=thr, alpha=alpha,
+            bias_threshold=0.5, logstd_min=latency_logstd_min, std_limit=std_limit,
+            use_mask=dec.use_latency_mask, weighted=latency_log_prob_weight)
+        base = Distribution(
+            {'safe': 'SafeNormal', 'biased': 'BiasedNormal', 'anomaly': 'AnomalyDetectionNormal',
+             'normal': 'Normal'}[mode],
+            mean=lambda: mean.reshape(shape4), std=lambda: std.reshape(shape4),
+            logstd=lambda: torch.log(std).reshape(shape4))
+        dist = Distribution('MaskedDistribution', base_distribution=base) \
+            if dec.use_latency_mask else base
+        net.add_node('latency', StochasticTensor(x.reshape(shape4), dist, ll.reshape(lead)))
+
+
 def _clip(x, lo, hi):
     if lo is None and hi is None:
         return x
@@ -805,7 +1016,13 @@ class TraceVAE(nn.Module):
           G: Optional[TraceGraphBatch] = None, n_z: Optional[int] = None, no_latency: bool = False,
           use_biased: bool = False, use_latency_biased: bool = False,
           latency_logstd_min: Optional[float] = None, latency_log_prob_weight: bool = False,
-          std_limit: Optional[torch.Tensor] = None) -> BayesianNet:
+          std_limit: Optional[torch.Tensor] = None,
+          eps: Optional[Mapping[str, torch.Tensor]] = None,
+          draws: Optional[Mapping[str, torch.Tensor]] = None) -> BayesianNet:
+        """p(...).  With `G`, every variable is observed (the chain of q).  Without it the
+        variables not in `observed` are drawn (prior sampling, evaluation.py:349); `eps`
+        (`z`, `z2`, `latency`: N(0,1) noise) and `draws` (`node_count`, `adj`, `node_type`:
+        the discrete outcomes) are extensions that pin the random choices for parity tests."""
         batch = None
         observed = dict(observed or {})
         if G is not None:
@@ -815,6 +1032,8 @@ class TraceVAE(nn.Module):
             observed['node_type'] = batch.node_type_pad
             observed['latency'] = batch.latency_pad[..., :C.LATENCY_DIM]
         net = BayesianNet(observed=observed)
+        net.meta['eps'] = dict(eps) if eps else None
+        net.meta['draws'] = dict(draws) if draws else None
         self.struct_vae.p(net, batch, n_z=n_z, use_biased=use_biased)
         if self.config.use_latency and not no_latency:
             self.latency_vae.p(net, batch, n_z=n_z, use_biased=use_biased and use_latency_biased,
