@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument('--score-k', type=int, default=10, help='n_z of the scoring leg (0 = skip)')
     ap.add_argument('--score-batch', type=int, default=128)
     ap.add_argument('--score-steps', type=int, default=3)
+    ap.add_argument('--prior-samples', type=int, default=128,
+                    help='traces drawn per call in the prior-sampling leg (N=1 only; 0 = skip)')
     ap.add_argument('--cpu-baseline-traces', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--gnn-width', type=int, default=None, help='per-head GAT width (default 500)')
@@ -227,6 +229,39 @@ def main():
                    'value': SB * world * args.score_steps / dt, 'unit': 'traces/s', 'n_z': K,
                    'batch_per_gpu': SB, 'n_gpus': world, 'ms_per_step': 1e3 * dt / args.score_steps}
 
+    # ---- prior-sampling leg (section 8f row 4; N=1 only, not part of `value`): p() without
+    # an observed graph, and the sampled-graph index kernels on their own against HBM
+    prior = None
+    if args.prior_samples > 0 and world == 1:
+        from tracevae_amd.batch import build_sampled_graphs
+        vae.eval()
+        n = args.prior_samples
+        with torch.no_grad():
+            net = vae.p(n_z=n)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(3):
+                net = vae.p(n_z=n)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - ts) / 3
+        adj = net['adj'].tensor.reshape(n, -1)
+        graph, _ = build_sampled_graphs(adj, M)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            build_sampled_graphs(adj, M)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        algo = 4.0 * adj.numel() + 8.0 * (5 * graph.num_edges + 2 * n * M + 1)
+        prior = {'metric': 'prior_sampled_traces_per_sec', 'value': n / dt, 'unit': 'traces/s',
+                 'samples_per_call': n, 'ms_per_call': 1e3 * dt,
+                 'sampled_graph_build': {'bound': 'hbm', 'edges': graph.num_edges,
+                                         'ms_incl_host_readback': ms,
+                                         'achieved': algo / (ms * 1e-3) / 1e9,
+                                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                         'frac': algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
     if rank == 0:
         value = B * world * args.steps / elapsed
         g = kernel_summary.get('gemm_f32', (0, 0.0, 0.0))
@@ -268,6 +303,7 @@ def main():
                        'num_operations': V, 'pool_traces_per_gpu': args.pool,
                        'parallelism': f'dp{world}'},
             'roofline': roof, 'other_kernels': others, 'scoring': scoring,
+            'prior_sampling': prior,
             'final_loss': float(loss_vals[-1]),
         }
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
