@@ -55,10 +55,11 @@ def test_edge_topologies(device):
         list(range(M - 1)),                   # chain with n = M
         [0, 0, 1, 1, 2, 2, 3],                # binary-ish tree
         [0, 1, 1, 1, 2, 5],                   # mixed
+        [],                                   # n = 1: a lone root (a generated trace can be one)
     ]
     flat, lr = hand_made_flat(shapes, 30, seed=5)
     _compare(flat, lr, 30, M)
-    _compare(flat, lr, 30, M, ids=[4, 0, 0, 2])     # repeats and reordering
+    _compare(flat, lr, 30, M, ids=[4, 0, 5, 0, 2, 5])     # repeats and reordering
 
 
 def test_large_max_node_count(device):

@@ -152,6 +152,28 @@ def test_eval_step_scores(device, use_flow, dims):
     assert rel_err(torch.cat([n1, n2]), nll) < 1e-5
 
 
+def test_eval_step_no_struct_scores_the_latency_model_alone(device):
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.evaluation import eval_step
+    V, M, K = 80, 20, 4
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 24, 2, 9, seed=7)
+    vae.eval()
+    B = len(flat)
+    g = torch.Generator().manual_seed(5)
+    eps = {'z': torch.randn(K, B, 10, generator=g), 'z2': torch.randn(K, B, 10, generator=g)}
+    G = TraceGraphBatch.from_store(store, np.arange(B), M)
+    loss, nll, full = eval_step(vae, G, K, eps=eps, return_chain=True)
+    loss_l, nll_l, chain = eval_step(vae, G, K, eps=eps, return_chain=True, no_struct=True)
+    assert list(chain.q) == ['z2'] and list(chain.p) == ['z2', 'latency']
+    # evaluation.py:132-142 on the remaining terms, composed with stock torch ops
+    w = (full.p['latency'].log_prob() + full.p['z2'].log_prob() - full.q['z2'].log_prob()).double()
+    assert rel_err(nll_l, -(torch.logsumexp(w, 0) - np.log(K))) < 1e-5
+    assert rel_err(loss_l, -w.mean(0)) < 1e-5
+    assert not torch.allclose(nll_l, nll)
+    with pytest.raises(ValueError):
+        eval_step(vae, G, K, eps=eps, no_struct=True, no_latency=True)
+
+
 def test_trainer_step_matches_oracle_update(device):
     """One full optimisation step (forward, backward, L2, clip, RMSprop) against the oracle +
     torch.optim.RMSprop on the CPU."""

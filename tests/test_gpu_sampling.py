@@ -185,7 +185,7 @@ def test_do_evaluate_prior(device, tmp_path):
     # 3 batches of 16 were drawn; what is not dropped is kept
     assert len(kept) == round(48 * (1.0 - res['drop_rate']))
     for g in kept:
-        assert 2 <= g.node_count <= M and g.node_count == g.root.count_nodes()
+        assert 1 <= g.node_count <= M and g.node_count == g.root.count_nodes()
         for _, node in g.iter_bfs():
             ops_ = [c.operation_id for c in node.children]
             assert ops_ == sorted(set(ops_)) and node.operation_id != 0

@@ -28,12 +28,20 @@ def eval_step(vae: TraceVAE, G: TraceGraphBatch, n_z: int, *, use_biased: bool =
               use_latency_biased: bool = True, no_latency: bool = False,
               std_limit: Optional[torch.Tensor] = None, latency_log_prob_weight: bool = False,
               latency_logstd_min: Optional[float] = None, clip_nll: Optional[float] = None,
-              eps=None, return_chain: bool = False):
-    """Returns `(loss [B], nll [B])` as device tensors (and the chain when asked)."""
+              eps=None, return_chain: bool = False, no_struct: bool = False):
+    """Returns `(loss [B], nll [B])` as device tensors (and the chain when asked).
+    `no_struct` scores the latency model alone: z and the structure terms are taken out of
+    both nets before the reduction (evaluation.py:132-139)."""
     chain = vae.q(G, n_z=n_z, no_latency=no_latency, eps=eps).chain(
         vae.p, latent_axis=0, G=G, use_biased=use_biased, use_latency_biased=use_latency_biased,
         no_latency=no_latency, latency_logstd_min=latency_logstd_min,
         latency_log_prob_weight=latency_log_prob_weight, std_limit=std_limit)
+    if no_struct:
+        if no_latency:
+            raise ValueError('no_struct and no_latency together leave nothing to score')
+        del chain.q['z']
+        for name in ('z', 'adj', 'node_count', 'node_type'):
+            del chain.p[name]
     loss, nll = chain.score(clip_nll)
     if return_chain:
         return loss, nll, chain
@@ -155,7 +163,8 @@ class DeviceCollector(object):
 
 def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: int,
                     use_biased: bool = True, use_latency_biased: bool = True,
-                    no_latency: bool = False, std_limit=None, latency_log_prob_weight: bool = False,
+                    no_latency: bool = False, no_struct: bool = False, std_limit=None,
+                    latency_log_prob_weight: bool = False,
                     latency_logstd_min: Optional[float] = None, clip_nll: Optional[float] = None,
                     test_threshold: Optional[float] = None,
                     nll_output_file: Optional[str] = None, labels: Optional[np.ndarray] = None,
@@ -177,8 +186,10 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
     loss_chunks: List[torch.Tensor] = []
     weights: List[int] = []
     label_chunks: List[np.ndarray] = []
+    # the reference skips every collector under no_struct (evaluation.py:161)
     collect = any(c is not None for c in (operation_id_dict_out, latency_std_dict_out,
-                                         latency_reldiff_dict_out)) and not no_latency
+                                         latency_reldiff_dict_out)) and not no_latency \
+        and not no_struct
     offset = 0
     try:
         for G in test_stream:
@@ -186,7 +197,8 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
                 vae, G, n_z, use_biased=use_biased, use_latency_biased=use_latency_biased,
                 no_latency=no_latency, std_limit=std_limit,
                 latency_log_prob_weight=latency_log_prob_weight,
-                latency_logstd_min=latency_logstd_min, clip_nll=clip_nll, return_chain=collect)
+                latency_logstd_min=latency_logstd_min, clip_nll=clip_nll, return_chain=collect,
+                no_struct=no_struct)
             loss, nll = res[0], res[1]
             nll_chunks.append(nll)
             loss_chunks.append(loss.mean().reshape(1))
@@ -255,11 +267,10 @@ def do_evaluate_prior(vae: TraceVAE, id_manager, latency_range, n_samples: int, 
     as dropped), the survivors are scored with the K-sample NLL and those at or above
     `nll_threshold` are dropped as well.  Writes `{'drop_rate': ...}` as JSON / YAML.
 
-    Two deliberate differences: the reference chains `vae.p` WITHOUT `G=G`
+    One deliberate difference: the reference chains `vae.p` WITHOUT `G=G`
     (evaluation.py:369-370), so its "NLL of the generated trace" is in fact the importance
     weight of yet another freshly drawn trace - here the generated traces are scored
-    themselves; and a generated trace of a single node is counted as dropped (the batching
-    kernel takes traces of two nodes and more).
+    themselves.
 
     `rng` feeds `p_net_to_trace_graphs`; with `return_samples` the kept traces are returned
     next to the result dict.  `latency_hist_out` only switches the per-operation latency
@@ -280,10 +291,7 @@ def do_evaluate_prior(vae: TraceVAE, id_manager, latency_range, n_samples: int, 
             max_node_count=vae.max_node_count)
         sample_count += len(graphs)
         drop_count += sum(g is None for g in graphs)
-        # a single node is no trace for the encoder (graph_vectors needs an edge)
-        lone = [g for g in graphs if g is not None and g.node_count < 2]
-        drop_count += len(lone)
-        graphs = [g for g in graphs if g is not None and g.node_count >= 2]
+        graphs = [g for g in graphs if g is not None]
         if not graphs:
             continue
         G = TraceGraphBatch(id_manager=id_manager, latency_range=latency_range,
