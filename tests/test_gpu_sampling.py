@@ -25,7 +25,7 @@ def _random_adj(graphs, m, density, seed):
 
 @pytest.mark.parametrize('graphs,m,density', [(1, 2, 0.5), (3, 2, None), (7, 5, None), (64, 32, 0.1),
                                               (33, 100, 0.02), (5, 100, None), (300, 17, 0.3),
-                                              (2, 300, 0.01), (0, 10, 0.5)])
+                                              (2, 300, 0.01), (2, 400, 0.01), (0, 10, 0.5)])
 def test_sampled_graph_build_is_bit_exact(device, graphs, m, density):
     from tracevae_amd.batch import build_sampled_graphs
     adj = _random_adj(graphs, m, density, seed=graphs * 1000 + m)

@@ -20,7 +20,35 @@ __device__ __forceinline__ int64_t tri(int64_t M, int64_t u, int64_t w) {
   return u * (2 * M - u - 1) / 2 + (w - u - 1);
 }
 
+// The per-node walks below read a graph's adjacency M times over, one dependent load per
+// trip: with STAGED the workgroup first copies it into LDS as bytes (one coalesced pass), which
+// is what fits for M up to ~350; longer traces read it from global memory (L2) instead.
+template <bool STAGED>
+struct Adjacency {
+  const float *A;
+  const uint8_t *S;
+  __device__ __forceinline__ bool operator()(int64_t t) const {
+    return STAGED ? S[t] != 0 : A[t] != 0.f;
+  }
+};
+
+// LDS: int32 ints[n_ints], then (STAGED) T bytes.  Returns true if a value is neither 0 nor 1.
+template <bool STAGED>
+__device__ __forceinline__ bool stage_adjacency(const float *A, int64_t T, uint8_t *S,
+                                                bool validate) {
+  bool bad = false;
+  if (STAGED || validate) {
+    for (int64_t t = threadIdx.x; t < T; t += SG_THREADS) {
+      const float x = A[t];
+      bad |= (x != 0.f && x != 1.f);
+      if (STAGED) S[t] = (x != 0.f);
+    }
+  }
+  return bad;
+}
+
 // degrees -> graph-local exclusive prefix sums (into indptr) and the graph's edge total
+template <bool STAGED>
 __global__ __launch_bounds__(SG_THREADS) void sg_count_kernel(int64_t M, const float *adj,
                                                               int64_t *indptr, int64_t *totals,
                                                               int32_t *status) {
@@ -28,18 +56,17 @@ __global__ __launch_bounds__(SG_THREADS) void sg_count_kernel(int64_t M, const f
   const int64_t g = blockIdx.x;
   const int64_t T = M * (M - 1) / 2;
   const float *A = adj + g * T;
-  int bad = 0;
+  uint8_t *S = reinterpret_cast<uint8_t *>(lds + (M + 1));
+  const bool bad = stage_adjacency<STAGED>(A, T, S, true);
+  if (bad) atomicOr(status, TV_SAMPLED_BAD_ADJ);
+  if (STAGED) __syncthreads();
+  const Adjacency<STAGED> nz{A, S};
   for (int64_t v = threadIdx.x; v < M; v += SG_THREADS) {
     int deg = 1;
-    for (int64_t u = 0; u < v; ++u) {
-      const float x = A[tri(M, u, v)];
-      deg += (x != 0.f);
-      bad |= (x != 0.f && x != 1.f);
-    }
-    for (int64_t w = v + 1; w < M; ++w) deg += (A[tri(M, v, w)] != 0.f);
+    for (int64_t u = 0; u < v; ++u) deg += nz(tri(M, u, v));
+    for (int64_t w = v + 1; w < M; ++w) deg += nz(tri(M, v, w));
     lds[v] = deg;
   }
-  if (bad) atomicOr(status, TV_SAMPLED_BAD_ADJ);
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
@@ -101,7 +128,8 @@ struct FillArgs {
   int32_t *rank;   // [G, T] scratch: position of an edge among the nonzeros of its row
 };
 
-// LDS (int32): lptr[M] colcnt[M] rowcnt[M] rowstart[M+1]
+// LDS (int32): lptr[M] colcnt[M] rowcnt[M] rowstart[M+1], then (STAGED) T bytes
+template <bool STAGED>
 __global__ __launch_bounds__(SG_THREADS) void sg_fill_kernel(FillArgs a) {
   extern __shared__ int32_t lds[];
   const int64_t g = blockIdx.x, M = a.M;
@@ -109,13 +137,17 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fill_kernel(FillArgs a) {
   const float *A = a.adj + g * T;
   int32_t *R = a.rank + g * T;
   int32_t *lptr = lds, *colcnt = lptr + M, *rowcnt = colcnt + M, *rowstart = rowcnt + M;
+  uint8_t *S = reinterpret_cast<uint8_t *>(rowstart + (M + 1));
   const int64_t E0 = a.offs[g];          // first edge (and first CSC position) of this graph
   const int64_t node0 = g * M;
+  stage_adjacency<STAGED>(A, T, S, false);
+  if (STAGED) __syncthreads();
+  const Adjacency<STAGED> nz{A, S};
 
   for (int64_t v = threadIdx.x; v < M; v += SG_THREADS) {
     int c = 0, r = 0;
-    for (int64_t u = 0; u < v; ++u) c += (A[tri(M, u, v)] != 0.f);
-    for (int64_t w = v + 1; w < M; ++w) r += (A[tri(M, v, w)] != 0.f);
+    for (int64_t u = 0; u < v; ++u) c += nz(tri(M, u, v));
+    for (int64_t w = v + 1; w < M; ++w) r += nz(tri(M, v, w));
     colcnt[v] = c;
     rowcnt[v] = r;
     lptr[v] = (int32_t)(a.indptr[node0 + v] - E0);
@@ -142,7 +174,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fill_kernel(FillArgs a) {
     int k = 0;
     for (int64_t w = u + 1; w < M; ++w) {
       const int64_t t = tri(M, u, w);
-      if (A[t] != 0.f) {
+      if (nz(t)) {
         const int64_t e = rowstart[u] + k;
         R[t] = k;
         a.src[E0 + e] = node0 + u;
@@ -170,7 +202,7 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fill_kernel(FillArgs a) {
     int c = 0, best = 0;
     for (int64_t u = 0; u < w; ++u) {
       const int64_t t = tri(M, u, w);
-      if (A[t] != 0.f) {
+      if (nz(t)) {
         const int k = R[t];
         const int64_t pf = E0 + lptr[w] + c;
         const int64_t pr = E0 + lptr[u] + colcnt[u] + k;
@@ -184,6 +216,12 @@ __global__ __launch_bounds__(SG_THREADS) void sg_fill_kernel(FillArgs a) {
     }
     a.node_idx[node0 + w] = best;
   }
+}
+
+// the byte copy of one adjacency next to the int32 arrays, within the 64 KB a launch gets
+// without asking for more
+inline bool staged_fits(size_t int_bytes, int64_t M) {
+  return int_bytes + (size_t)(M * (M - 1) / 2) <= 64 * 1024;
 }
 
 }  // namespace
@@ -218,8 +256,13 @@ extern "C" int tv_sampled_graph_count(int64_t graphs, int64_t max_node_count, co
   }
   int64_t *totals = (int64_t *)ws;
   const int64_t M = max_node_count;
-  hipLaunchKernelGGL(sg_count_kernel, dim3((unsigned)graphs), dim3(SG_THREADS),
-                     sizeof(int32_t) * (size_t)(M + 1), s, M, adj, indptr, totals, status);
+  const size_t ints = sizeof(int32_t) * (size_t)(M + 1);
+  if (staged_fits(ints, M))
+    hipLaunchKernelGGL(sg_count_kernel<true>, dim3((unsigned)graphs), dim3(SG_THREADS),
+                       ints + (size_t)(M * (M - 1) / 2), s, M, adj, indptr, totals, status);
+  else
+    hipLaunchKernelGGL(sg_count_kernel<false>, dim3((unsigned)graphs), dim3(SG_THREADS), ints, s,
+                       M, adj, indptr, totals, status);
   TV_LAUNCH_CHECK("tv_sampled_graph_count");
   hipLaunchKernelGGL(sg_scan_kernel, dim3(1), dim3(SG_THREADS), 0, s, graphs, totals,
                      graph_edge_offsets);
@@ -259,8 +302,13 @@ extern "C" int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int
   a.src = src; a.dst = dst; a.indices = indices; a.eids = eids; a.rev = rev;
   a.node_idx = node_idx;
   a.rank = (int32_t *)((int64_t *)ws + (graphs + 1));
-  hipLaunchKernelGGL(sg_fill_kernel, dim3((unsigned)graphs), dim3(SG_THREADS),
-                     sizeof(int32_t) * (size_t)(4 * M + 1), (hipStream_t)stream, a);
+  const size_t ints = sizeof(int32_t) * (size_t)(4 * M + 1);
+  if (staged_fits(ints, M))
+    hipLaunchKernelGGL(sg_fill_kernel<true>, dim3((unsigned)graphs), dim3(SG_THREADS),
+                       ints + (size_t)T, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(sg_fill_kernel<false>, dim3((unsigned)graphs), dim3(SG_THREADS), ints,
+                       (hipStream_t)stream, a);
   TV_LAUNCH_CHECK("tv_sampled_graph_fill");
   return TV_OK;
 }
