@@ -333,6 +333,44 @@ def test_evaluate_nll_flow_thresholds_and_std_limit(device, tmp_path):
     assert lim[op] == np.float32(1.5 * float(np.percentile(want_std[sel], 99.0)))
 
 
+def test_structure_collectors_follow_the_reference_loops(device):
+    """p_node_count / p_edge collectors of do_evaluate_nll against the per-trace loops of
+    tensor_utils.py:171-198 written out in NumPy on the chain's own tensors."""
+    from tracevae_amd.batch import DeviceTraceStore
+    from tracevae_amd.evaluation import DeviceCollector, do_evaluate_nll, eval_step
+    from tracevae_amd.graph_utils import triu_to_dense
+    from tracevae_amd.train import StoreStream
+    V, M = 40, 16
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 2, 11, seed=17,
+                                                       anomaly_ratio=0.5)
+    vae.eval()
+    pn, pe = DeviceCollector('t_'), DeviceCollector('t_')
+    torch.manual_seed(3)
+    do_evaluate_nll(StoreStream(store, 4, max_node_count=M), vae, 2, p_node_count_dict_out=pn,
+                    p_edge_dict_out=pe)
+    torch.manual_seed(3)
+    want_n = {0: [], 1: [], 2: []}
+    want_e = {0: [], 1: [], 2: []}
+    for G in StoreStream(store, 4, max_node_count=M):
+        _, _, chain = eval_step(vae, G, 2, return_chain=True)
+        probs = chain.p['node_count'].distribution.probs[0].cpu().numpy()
+        count = chain.p['node_count'].tensor.cpu().numpy()
+        p_edge = chain.p['adj'].distribution.probs[0].cpu().numpy()
+        truth = chain.p['adj'].tensor.cpu().numpy()
+        for i, lab in enumerate(G.labels):
+            k = int(count[i])
+            want_n[int(lab)].append(probs[i, k])
+            cur_p = triu_to_dense(p_edge[i], M)[:k, :k]
+            cur_t = triu_to_dense(truth[i], M)[:k, :k]
+            want_e[int(lab)].append(np.abs((1.0 - cur_t) - cur_p).reshape(-1))
+    assert sum(len(v) for v in want_n.values()) == 11 and len(want_n[0]) and len(want_n[0]) < 11
+    for code, name in DeviceCollector.CATEGORIES:
+        got_n, got_e = pn.array('t_' + name), pe.array('t_' + name)
+        assert np.allclose(got_n, np.asarray(want_n[code], np.float32), rtol=1e-6, atol=0)
+        ref_e = np.concatenate(want_e[code]) if want_e[code] else np.zeros([0], np.float32)
+        assert got_e.shape == ref_e.shape and np.allclose(got_e, ref_e, rtol=1e-6, atol=1e-7)
+
+
 def test_learning_rate_schedule_follows_the_finished_epoch_count(device):
     """train.py:374-383: the rate is set when an epoch ENDS, from the number of finished epochs,
     so epoch e runs at initial_lr * ratio ** ((e - 1) // anneal_epochs); phase 2 starts a new

@@ -149,6 +149,15 @@ class DeviceCollector(object):
             sel = real & (lab == code)[:, None]
             self.chunks.setdefault(self.prefix + name, []).append(values_bm[sel])
 
+    def add_selected(self, values: torch.Tensor, keep: torch.Tensor, labels: np.ndarray) -> None:
+        """values / keep [B, ...]: the kept entries of every trace, in trace order, row-major
+        within a trace."""
+        lab = torch.as_tensor(np.asarray(labels), device=values.device)
+        shape = (-1,) + (1,) * (values.dim() - 1)
+        for code, name in self.CATEGORIES:
+            sel = keep & (lab == code).reshape(shape)
+            self.chunks.setdefault(self.prefix + name, []).append(values[sel])
+
     def array(self, key: str, group=None) -> np.ndarray:
         """All collected values of `key`; with a process group (sharded scoring) the shards of
         every rank, concatenated in rank order."""
@@ -171,15 +180,18 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
                     operation_id_dict_out: Optional[DeviceCollector] = None,
                     latency_std_dict_out: Optional[DeviceCollector] = None,
                     latency_reldiff_dict_out: Optional[DeviceCollector] = None,
+                    p_node_count_dict_out: Optional[DeviceCollector] = None,
+                    p_edge_dict_out: Optional[DeviceCollector] = None,
                     process_group=None, **_ignored) -> Dict[str, float]:
     """The scoring driver (evaluation.py:40-283): score every batch of the stream, keep scores
     and collected per-node values on the GPU until the end (one device->host copy each), then
     the summary of `analyze_anomaly_nll` and the optional `.npz` (`nll_list`, `label_list`,
     `anomaly_degree = nll / best_threshold_latency`, evaluation.py:276-283).  The three
     collectors feed test.py's std-limit / bias-std inference (operation id, predicted latency
-    std and |latency - mean| / std of every real node, by trace label).  The plotting and
-    p_node_count / p_edge collectors of the reference are diagnostics outside this path:
-    accepted and ignored."""
+    std and |latency - mean| / std of every real node, by trace label); `p_node_count_dict_out`
+    gathers p(node_count = observed) and `p_edge_dict_out` the |(1 - adj) - p(edge)| entries of
+    every trace's dense n x n block, both of sample 0 (tensor_utils.py:171-198).  The
+    plotting / TensorBoard arguments of the reference are accepted and ignored."""
     was_training = vae.training
     vae.eval()
     nll_chunks: List[torch.Tensor] = []
@@ -187,9 +199,12 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
     weights: List[int] = []
     label_chunks: List[np.ndarray] = []
     # the reference skips every collector under no_struct (evaluation.py:161)
-    collect = any(c is not None for c in (operation_id_dict_out, latency_std_dict_out,
-                                         latency_reldiff_dict_out)) and not no_latency \
+    collect_lat = any(c is not None for c in (operation_id_dict_out, latency_std_dict_out,
+                                             latency_reldiff_dict_out)) and not no_latency \
         and not no_struct
+    collect_struct = any(c is not None for c in (p_node_count_dict_out, p_edge_dict_out)) \
+        and not no_struct
+    collect = collect_lat or collect_struct
     offset = 0
     try:
         for G in test_stream:
@@ -208,7 +223,26 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
                 step_labels = np.zeros(len(nll), np.int64)
             label_chunks.append(np.asarray(step_labels))
             offset += len(nll)
-            if collect:
+            if collect_struct:
+                chain, batch = res[2], G.build_dgl()
+                count = batch.node_count
+                if p_node_count_dict_out is not None:
+                    probs = chain.p['node_count'].distribution.probs[0]
+                    picked = probs.gather(1, count[:, None])[:, 0]
+                    p_node_count_dict_out.add_selected(picked, torch.ones_like(picked, dtype=torch.bool),
+                                                       step_labels)
+                if p_edge_dict_out is not None:
+                    m = batch.max_node_count
+                    iu = torch.triu_indices(m, m, 1, device=count.device)
+                    # triu_to_dense pads with zeros: below the diagonal |(1 - 0) - 0| = 1
+                    dense = torch.ones([len(count), m, m], device=count.device)
+                    dense[:, iu[0], iu[1]] = \
+                        ((1.0 - batch.adj) - chain.p['adj'].distribution.probs[0]).abs()
+                    slot = torch.arange(m, device=count.device)
+                    real = slot[None, :] < count[:, None]
+                    p_edge_dict_out.add_selected(dense, real[:, :, None] & real[:, None, :],
+                                                 step_labels)
+            if collect_lat:
                 chain, batch = res[2], G.build_dgl()
                 count = batch.node_count
                 if operation_id_dict_out is not None:
