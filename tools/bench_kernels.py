@@ -53,6 +53,12 @@ def bench_gemm():
         ('square 4096', False, True, 4096, 4096, 4096),
         ('fwd  x.W^T dec (again)', False, True, 51200, 1000, 1000),
         ('fwd  1024-aligned', False, True, 51200, 1024, 1024),
+        # scoring: K * B * M = 10 * 128 * 100 decoder rows
+        ('score x.W^T', False, True, 128000, 1000, 1000),
+        ('score x.W', False, False, 128000, 1000, 1000),
+        ('score logits V=1001', False, False, 128000, 1001, 1000),
+        ('score x.W^T 64k rows', False, True, 64000, 1000, 1000),
+        ('score x.W^T 256k rows', False, True, 256000, 1000, 1000),
     ]
     for name, ta, tb, m, n, k in shapes:
         a = torch.randn((k, m) if ta else (m, k), device=DEV)
