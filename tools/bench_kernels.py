@@ -123,18 +123,6 @@ def bench_norm():
     with torch.no_grad():
         ms = timeit(lambda: ops.bn_lrelu(x, gamma, beta, rm, rv, True, 1e-6))
     print(f'bn_lrelu train fwd (stats+finalize+apply): {ms:.3f} ms  {12.0 * rows * C / ms / 1e6:.0f} GB/s', flush=True)
-    nblk = hip.query('tv_stat_blocks', rows)
-    part = torch.empty(nblk, 2, C, device=DEV)
-    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-    ms = timeit(lambda: hip.call('tv_colstats', rows, C, hip.ptr(x), hip.ptr(part)))
-    print(f'  colstats: {ms:.3f} ms  {4.0 * rows * C / ms / 1e6:.0f} GB/s', flush=True)
-    ms = timeit(lambda: hip.call('tv_bn_finalize', C, nblk, hip.ptr(part), rows, 1e-6, 0.1, hip.ptr(mean),
-                                 hip.ptr(rstd), hip.ptr(rm), hip.ptr(rv)))
-    print(f'  bn_finalize: {ms:.3f} ms', flush=True)
-    y = torch.empty_like(x)
-    ms = timeit(lambda: hip.call('tv_bn_apply_lrelu', rows, C, hip.ptr(x), hip.ptr(mean), hip.ptr(rstd),
-                                 hip.ptr(gamma), hip.ptr(beta), 0.01, hip.ptr(y)))
-    print(f'  bn_apply_lrelu: {ms:.3f} ms  {8.0 * rows * C / ms / 1e6:.0f} GB/s', flush=True)
     out = ops.bn_lrelu(x, gamma, beta, rm, rv, True, 1e-6)
     dy = torch.randn_like(out)
     ms = timeit(lambda: torch.autograd.grad(out, [x, gamma, beta], dy, retain_graph=True))
