@@ -1,0 +1,91 @@
+"""Data-parallel training step with two ranks on the GPU: each rank steps
+on its own shard of traces, the flat gradient bucket is averaged over the ranks, every rank
+applies the same update.  The ranks share the one GPU of the test box and talk over gloo (the
+RCCL branch of `Trainer.all_reduce_gradients` is the same call with another backend); the
+expectation is built in this process from two single-rank backward passes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_config, make_flat
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+V, M, WIDTH, LAYERS, PER_RANK = 40, 12, 16, 2, 6
+
+
+def _trainer(device, world):
+    from tracevae_amd.model import TraceVAE
+    from tracevae_amd.train import Trainer
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    cfg = make_config(width=WIDTH, layers=LAYERS)
+    vae = TraceVAE(cfg.model, V, max_node_count=M)
+    for m in vae.modules():
+        if hasattr(m, 'initialized'):
+            m.initialized = True
+    vae.to(device)
+    return Trainer(vae, cfg, world_size=world)
+
+
+def _shard(rank):
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    flat, lr = make_flat(2 * PER_RANK, V, M, seed=21)
+    store = DeviceTraceStore(flat, lr, V)
+    ids = np.arange(rank * PER_RANK, (rank + 1) * PER_RANK)
+    gen = torch.Generator().manual_seed(50 + rank)
+    eps = {'z': torch.randn(PER_RANK, 10, generator=gen), 'z2': torch.randn(PER_RANK, 10, generator=gen)}
+    return TraceGraphBatch.from_store(store, ids, M), eps
+
+
+def _dp_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    trainer = _trainer(device, world)
+    G, eps = _shard(rank)
+    out = trainer.step(G, eps=eps)
+    torch.save({'flat': trainer.flat.flat.detach().cpu(), 'loss': out['loss'].cpu(),
+                'buffers': {k: v.cpu() for k, v in trainer.vae.named_buffers()}},
+               os.path.join(tmp, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_averaged_gradients(device, tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, 31000 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
+
+    # the same in one process: per-shard gradients (L2 term included), their mean, one update
+    grads, losses, refs = [], [], []
+    for rank in range(world):
+        tr = _trainer(device, 1)
+        G, eps = _shard(rank)
+        seen = {}
+        tr.all_reduce_gradients = lambda tr=tr, seen=seen: seen.update(g=tr.flat.grad.clone())
+        tr.optimizer.step = lambda *a, **k: None
+        losses.append(tr.step(G, eps=eps)['loss'].cpu())
+        grads.append(seen['g'])
+        refs.append(tr)
+    mean = (grads[0] + grads[1]) / 2
+    for rank in range(world):
+        tr = _trainer(device, 1)
+        G, eps = _shard(rank)
+        tr.all_reduce_gradients = lambda tr=tr: tr.flat.grad.copy_(mean)
+        tr.step(G, eps=eps)
+        want = tr.flat.flat.detach().cpu()
+        assert torch.allclose(got[rank]['flat'], want, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(got[rank]['loss'], losses[rank], rtol=1e-6)
+        # BatchNorm statistics stay per rank (no sync-BN), parameters do not
+        for k, v in tr.vae.named_buffers():
+            assert torch.allclose(got[rank]['buffers'][k].float(), v.cpu().float(), rtol=1e-6, atol=1e-7), k
+    assert torch.equal(got[0]['flat'], got[1]['flat'])
+    assert not torch.allclose(grads[0], grads[1])
+    assert any(not torch.equal(got[0]['buffers'][k], got[1]['buffers'][k])
+               for k in got[0]['buffers'] if k.endswith('running_mean'))
