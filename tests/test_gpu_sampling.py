@@ -84,7 +84,10 @@ def _model(device, V, M, width, layers, seed=0, extra=()):
 
 @pytest.mark.parametrize('use_flow,dims', [(True, (60, 16, 16, 2, 9)), (False, (60, 16, 16, 2, 9)),
                                            # BASELINE configs[1] dims
-                                           (True, (1001, 100, None, None, 6))])
+                                           (True, (1001, 100, None, None, 6)),
+                                           # long traces (configs[4] node count): the adjacency
+                                           # no longer fits LDS in the graph build
+                                           (True, (200, 500, 16, 2, 3))])
 def test_prior_sample_matches_oracle(device, use_flow, dims):
     from oracle.model import OracleTraceVAE
     V, M, width, layers, n = dims
