@@ -33,6 +33,10 @@ extern "C" {
 #define TV_ERR_LAUNCH (-2)  /* HIP reported a launch error */
 #define TV_ERR_WORKSPACE (-3) /* workspace too small */
 
+/* limits of tv_train_loss_* */
+#define TV_LOSS_MAX_VECTORS 8
+#define TV_LOSS_MAX_LATENTS 2
+
 /* limits of tv_realnvp_logprob_* */
 #define TV_FLOW_MAX_LEVELS 8
 #define TV_FLOW_MAX_DIM 20
@@ -451,6 +455,27 @@ int tv_optim_step(int kind, int64_t n, float *param, const float *grad, float *s
                   float *state2, const float *grad_norm /* device scalar, nullable */,
                   float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step,
                   void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * the scalar end of train_step (tracegnn/models/trace_vae/train.py:229-270):
+ *   recons = mean_b sum_{kind 0} vec[b];  kl = mean_b (sum_{kind 1} vec[b] - sum_{kind 2} vec[b])
+ *   loss = beta * kl - recons + l2_reg * l2_value[0]
+ *          + sum_t z_regs[t] * (mean_b m_b^2 + mean_b (v_b - 1)^2),
+ *   (m_b, v_b) = mean / biased variance of zs[t][b, :]  (get_moments, tensor_utils.py:117-125;
+ *   the z_unit_ball_reg terms of train.py:259-270).
+ * vecs: n_vec device vectors [batch] (log p(x) of the observed variables: kind 0, log q of the
+ * latents: kind 1, log p of the latents: kind 2); the tables themselves are host arrays.
+ * out3 (device) = loss, recons, kl.  bwd: d(loss)/d(vecs[i]) into dvecs[i], d(loss)/d(zs[t])
+ * (regulariser only) into dzs[t], scaled by dloss[0] (device); NULL entries are skipped.
+ * ---------------------------------------------------------------------------------- */
+int tv_train_loss_fwd(int64_t batch, int n_vec, const float *const *vecs, const int *kinds,
+                      int n_z, const float *const *zs, const int64_t *z_dims,
+                      const float *z_regs, const float *l2_value, float l2_reg, float beta,
+                      float *out3, void *stream);
+int tv_train_loss_bwd(int64_t batch, int n_vec, const float *const *vecs, const int *kinds,
+                      float *const *dvecs, int n_z, const float *const *zs,
+                      const int64_t *z_dims, const float *z_regs, float *const *dzs, float beta,
+                      const float *dloss, void *stream);
 
 #ifdef __cplusplus
 }

@@ -235,6 +235,51 @@ def test_gat_replicas_and_eval_epilogue(device):
     assert rel_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize('batch,n_lat,use_l2,beta', [(700, 2, True, 1.0), (9, 1, False, 0.25),
+                                                     (1, 0, True, 1.0), (512, 2, True, 0.5)])
+def test_train_loss_matches_composition(device, batch, n_lat, use_l2, beta):
+    """tv_train_loss_fwd/bwd against train.py:229-270 composed from tensor ops (float64)."""
+    from tracevae_amd import ops
+    names = ['node_count', 'adj', 'node_type', 'latency', 'qz', 'qz2', 'pz', 'pz2']
+    vec = {n: _rand(batch, seed=10 + i) * 50 for i, n in enumerate(names)}
+    obs, ql, pl = names[:4], names[4:4 + max(n_lat, 1)], names[6:6 + max(n_lat, 1)]
+    zs = [_rand(batch, d, seed=30 + i) for i, d in enumerate((10, 20)[:n_lat])]
+    regs = [1.0, 0.3][:n_lat]
+    l2, l2_reg = _rand(1, seed=40).abs() * 100, 1e-4
+
+    def run(dtype, dev, fused):
+        v = {n: t.detach().clone().to(dtype).to(dev).requires_grad_(True) for n, t in vec.items()}
+        z = [t.detach().clone().to(dtype).to(dev).requires_grad_(True) for t in zs]
+        l2d = l2.to(dtype).to(dev)
+        if fused:
+            loss, recons, kl = ops.train_loss([v[n] for n in obs], [v[n] for n in ql],
+                                              [v[n] for n in pl], beta, l2d if use_l2 else None,
+                                              l2_reg if use_l2 else 0.0, list(zip(z, regs)))
+        else:
+            recons = sum(v[n] for n in obs).mean()
+            kl = (sum(v[n] for n in ql) - sum(v[n] for n in pl)).mean()
+            loss = beta * kl - recons
+            if use_l2:
+                loss = loss + l2_reg * l2d[0]
+            for t, r in zip(z, regs):
+                m = t.mean(-1)
+                var = (t * t).mean(-1) - m * m
+                loss = loss + r * ((m * m).mean() + ((var - 1) ** 2).mean())
+        (loss * 3.0).backward()
+        used = obs + ql + pl
+        return loss, recons, kl, [v[n].grad for n in used], [t.grad for t in z]
+
+    ref = run(torch.float64, 'cpu', False)
+    got = run(torch.float32, device, True)
+    for a, b in zip(got[:3], ref[:3]):
+        assert rel_err(a.detach(), b.detach()) < TOL
+    for a, b in zip(got[3] + got[4], ref[3] + ref[4]):
+        assert rel_err(a, b) < TOL
+    assert not got[1].requires_grad and not got[2].requires_grad
+    again = run(torch.float32, device, True)
+    assert torch.equal(again[0], got[0])
+
+
 # --------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize('rows,cols', [(300, 1000), (77, 250), (5000, 16)])
 def test_bn_lrelu_train_and_eval(device, rows, cols):

@@ -912,6 +912,70 @@ def realnvp_log_prob(z, params, levels: int, hidden: int, slope: float):
     return _RealNVPLogProb.apply(z, levels, hidden, slope, *params)
 
 
+class _TrainLoss(Function):
+    """(loss, recons, kl) of train_step from the chain's log-prob vectors, one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, kinds, regs, beta, l2_value, l2_reg, n_vec, *tensors):
+        import ctypes
+        vecs = [_check(t.reshape(-1), 'log_prob') for t in tensors[:n_vec]]
+        zs = [_check(t, 'z') for t in tensors[n_vec:]]
+        batch = vecs[0].shape[0]
+        for v in vecs:
+            if v.shape[0] != batch:
+                raise ValueError('train_loss: log-prob vectors of different lengths')
+        for z in zs:
+            if z.dim() != 2 or z.shape[0] != batch:
+                raise ValueError(f'train_loss: latent of shape {tuple(z.shape)} for batch {batch}')
+        out = torch.empty([3], dtype=_f32, device=vecs[0].device)
+        ctx.tables = (
+            (ctypes.c_void_p * len(vecs))(*[v.data_ptr() for v in vecs]),
+            (ctypes.c_int * len(vecs))(*kinds),
+            (ctypes.c_void_p * max(len(zs), 1))(*[z.data_ptr() for z in zs]),
+            (ctypes.c_int64 * max(len(zs), 1))(*[z.shape[1] for z in zs]),
+            (ctypes.c_float * max(len(zs), 1))(*regs))
+        vt, kt, zt, dt, rt = ctx.tables
+        hip.call('tv_train_loss_fwd', batch, len(vecs), vt, kt, len(zs), zt, dt, rt,
+                 hip.ptr(l2_value), float(l2_reg), float(beta), hip.ptr(out))
+        ctx.save_for_backward(*vecs, *zs)
+        ctx.meta = (batch, len(vecs), len(zs), float(beta), [t.shape for t in tensors])
+        loss, recons, kl = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(recons, kl)
+        return loss, recons, kl
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss, _dr, _dk):
+        import ctypes
+        batch, n_vec, n_z, beta, shapes = ctx.meta
+        saved = ctx.saved_tensors
+        need = ctx.needs_input_grad[6:]
+        dev = saved[0].device
+        dloss = _check(dloss.reshape(1), 'dloss')
+        grads = [torch.empty_like(t) if w else None for t, w in zip(saved, need)]
+        vt, kt, zt, dt, rt = ctx.tables
+        gv = (ctypes.c_void_p * n_vec)(*[g.data_ptr() if g is not None else None
+                                         for g in grads[:n_vec]])
+        gz = (ctypes.c_void_p * max(n_z, 1))(*[g.data_ptr() if g is not None else None
+                                               for g in grads[n_vec:]])
+        hip.call('tv_train_loss_bwd', batch, n_vec, vt, kt, gv, n_z, zt, dt, rt, gz, beta,
+                 hip.ptr(dloss))
+        out = [g.reshape(sh) if g is not None else None for g, sh in zip(grads, shapes)]
+        return (None, None, None, None, None, None) + tuple(out)
+
+
+def train_loss(obs, q_latent, p_latent, beta: float, l2_value=None, l2_reg: float = 0.0,
+               latents=()):
+    """train.py:229-270 in one kernel: `obs` / `q_latent` / `p_latent` are lists of log-prob
+    vectors [B]; `latents` is a list of `(z [B, D], reg)` for the unit-ball regulariser.
+    Returns `(loss, recons, kl)` scalars; only `loss` carries gradients."""
+    vecs = list(obs) + list(q_latent) + list(p_latent)
+    kinds = [0] * len(obs) + [1] * len(q_latent) + [2] * len(p_latent)
+    zs = [z for z, _ in latents]
+    regs = [float(r) for _, r in latents]
+    return _TrainLoss.apply(kinds, regs, beta, l2_value, l2_reg, len(vecs), *vecs, *zs)
+
+
 LATENCY_MODES = {'normal': 0, 'safe': 1, 'biased': 2, 'anomaly': 3}
 
 
