@@ -31,7 +31,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, fp32 matrix (dense)
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per GEMM launch of the default workload, from the committed --pmc passes
 # (tools/summarize_profile.py traffic; FETCH_SIZE x2 + WRITE_SIZE, separate passes)
-TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r01i_hbm_traffic.json')
+TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r01k_hbm_traffic.json')
 
 
 def measured_traffic(args):
@@ -271,7 +271,7 @@ def main():
             roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel', 'achieved': tf,
                     'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': tf / F32_MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(args),
-                    'traffic_unit': 'bytes/launch (profiles/r01i_hbm_traffic.json)',
+                    'traffic_unit': 'bytes/launch (profiles/r01k_hbm_traffic.json)',
                     'launches': g[0], 'avg_ms': g[2] / max(g[0], 1),
                     'share_of_step': g[2] * 1e-3 / elapsed}
             # the same figure for the shapes that carry the time (the aggregate above also
