@@ -347,11 +347,15 @@ class _GATConv(Function):
         if stats is None:
             stats = torch.empty([0], dtype=_f32, device=dev)
         ctx.mark_non_differentiable(stats)
+        # no zero-filled gradient tensor for the statistics output on the way back
+        ctx.set_materialize_grads(False)
         return out, stats
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout, _dstats):
+        if dout is None:
+            return (None,) * 12
         ft, el, er, alpha, al, ar = ctx.saved_tensors
         g = ctx.graph
         heads, feats = ctx.hf
@@ -791,11 +795,14 @@ class _NormalReparam(Function):
         ctx.save_for_backward(logstd_raw, eps)
         ctx.args = (k, batch, dim, lo, hi)
         ctx.mark_non_differentiable(logstd)
+        ctx.set_materialize_grads(False)
         return z, logq, logstd
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dz, dlogq, _dlogstd):
+        if dz is None and dlogq is None:
+            return None, None, None, None, None
         logstd_raw, eps = ctx.saved_tensors
         k, batch, dim, lo, hi = ctx.args
         dz = _check(dz, 'dz') if dz is not None else None
@@ -941,6 +948,7 @@ class _TrainLoss(Function):
         ctx.meta = (batch, len(vecs), len(zs), float(beta), [t.shape for t in tensors])
         loss, recons, kl = out[0], out[1], out[2]
         ctx.mark_non_differentiable(recons, kl)
+        ctx.set_materialize_grads(False)
         return loss, recons, kl
 
     @staticmethod
@@ -948,6 +956,8 @@ class _TrainLoss(Function):
     def backward(ctx, dloss, _dr, _dk):
         import ctypes
         batch, n_vec, n_z, beta, shapes = ctx.meta
+        if dloss is None:
+            return (None,) * (6 + len(shapes))
         saved = ctx.saved_tensors
         need = ctx.needs_input_grad[6:]
         dev = saved[0].device
@@ -996,11 +1006,14 @@ class _LatencyLL(Function):
         ctx.has_limit = std_limit is not None
         ctx.n_samples, ctx.cfg = n_samples, cfg
         ctx.mark_non_differentiable(std_out)
+        ctx.set_materialize_grads(False)
         return ll, std_out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dll, _dstd):
+        if dll is None:
+            return (None,) * 8
         feats, latency_pad, node_count, node_type_pad, std_limit = ctx.saved_tensors
         if not ctx.has_limit:
             std_limit = None
