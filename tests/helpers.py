@@ -102,3 +102,27 @@ def rel_err(a, b):
     b = torch.as_tensor(b, dtype=torch.float64).cpu()
     denom = b.abs().max().clamp(min=1e-12)
     return float((a - b).abs().max() / denom)
+
+
+def golden_sample_flat():
+    """The 17 traces of the reference's `sample_dataset`, as the reference's own
+    `graph_vectors()` produced them (tests/golden/sample_dataset_vectors.json), as one
+    `FlatTraces` + the data set's latency ranges.  Returns (flat, latency_range, V, graphs)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                        'sample_dataset_vectors.json')
+    with open(path, 'r', encoding='utf-8') as f:
+        golden = json.load(f)
+    graphs = [g for entry in golden['sets'].values() for g in entry['graphs']]
+    off = np.zeros(len(graphs) + 1, dtype=np.int64)
+    np.cumsum([g['node_count'] for g in graphs], out=off[1:])
+    cat = lambda k, dt: np.concatenate([np.asarray(g[k], dtype=dt) for g in graphs])
+    flat = FlatTraces(node_offsets=off, u=cat('u', np.int64), v=cat('v', np.int64),
+                      node_type=cat('node_type', np.int64),
+                      avg_latency=cat('avg_latency', np.float32),
+                      max_latency=cat('max_latency', np.float32),
+                      min_latency=cat('min_latency', np.float32))
+    lr = TraceGraphLatencyRangeFile(
+        latency_data={int(k): v for k, v in golden['latency_range'].items()})
+    return flat, lr, golden['num_operations'], graphs

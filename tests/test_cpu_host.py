@@ -267,3 +267,134 @@ def test_flat_dataset_files_round_trip(tmp_path):
     assert len(both) == 8 and int(both.node_offsets[-1]) == int(a.node_offsets[-1] + b.node_offsets[-1])
     assert np.array_equal(both.node_type[int(a.node_offsets[-1]):], b.node_type)
     assert np.array_equal(both.labels, np.concatenate([a.labels, b.labels]))
+
+
+# ---------------------------------------------------------------------------------------
+# data-parallel epoch loop: equal step counts, one collective per step, collective NaN vote
+# ---------------------------------------------------------------------------------------
+def _spawn_with_deadline(fn, args, nprocs, seconds=120):
+    """mp.spawn that cannot hang the suite: a rank blocked in an unmatched collective is
+    killed at the deadline and the test fails."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.time() + seconds
+    while not ctx.join(timeout=1.0):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+            pytest.fail('a rank was still blocked (unmatched collective?) at the deadline')
+
+
+class _FakeStore(object):
+    labels = None
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+def _epoch_loop_worker(rank, world, port, tmp, nan_at):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from tracevae_amd.model import TraceVAE
+    from tracevae_amd.train import NANLossError, StoreStream, Trainer, run_training
+    torch.manual_seed(0)
+    cfg = make_config(width=8, layers=2)
+    cfg.train.max_epoch, cfg.train.struct_pretrain_epochs = 3, 1
+    vae = TraceVAE(cfg.model, 30, max_node_count=8)
+
+    log = []
+
+    class HostTrainer(Trainer):
+        """The real step skeleton (exchange, NaN vote) around stand-ins for the two GPU parts."""
+
+        def local_gradients(self, G, eps=None):
+            i = G._stream_index
+            self.flat.grad.fill_(float(100 * self.epoch + 10 * i + rank))
+            bad = nan_at is not None and (self.epoch, i) == nan_at
+            return {'loss': torch.tensor(float('nan') if bad else float(i))}
+
+        def update(self):
+            log.append((self.epoch, self.latency_only, self.flat.grad.clone()))
+
+    trainer = HostTrainer(vae, cfg, world_size=world)
+    # 7 batches of 10 traces (the last one short): 7 % 2 == 1, the case that used to deadlock
+    stream = StoreStream(_FakeStore(65), 10, shuffle=True, seed=3, rank=rank, world_size=world,
+                         equal_steps=True)
+    raised = None
+    try:
+        run_training(trainer, stream, cfg.train, cfg.train.struct_pretrain_epochs, log=lambda m: None)
+    except NANLossError as ex:
+        raised = ex.epoch
+    torch.save({'log': log, 'raised': raised, 'tail': trainer.flat.tail_start,
+                'batch_count': stream.batch_count, 'total': stream.total_batches},
+               os.path.join(tmp, f'r{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_epoch_loop_equal_steps_across_phase_switch_gloo(tmp_path):
+    world, port = 2, 33000 + os.getpid() % 2000
+    _spawn_with_deadline(_epoch_loop_worker, (world, port, str(tmp_path), None), world)
+    r = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
+    assert r[0]['total'] == r[1]['total'] == 6 and r[0]['batch_count'] == r[1]['batch_count'] == 3
+    assert r[0]['raised'] is None and r[1]['raised'] is None
+    assert len(r[0]['log']) == len(r[1]['log']) == 9            # 3 epochs x 3 steps on each rank
+    tail = r[0]['tail']
+    for step, (a, b) in enumerate(zip(r[0]['log'], r[1]['log'])):
+        epoch, i0 = 1 + step // 3, 2 * (step % 3)
+        assert a[0] == b[0] == epoch and a[1] == b[1] == (epoch > 1)
+        mean = 100.0 * epoch + 10.0 * (i0 + 0.5) + 0.5        # ranks hold batches i0 and i0 + 1
+        start = tail if epoch > 1 else 0                       # phase 2 exchanges the suffix only
+        assert torch.all(a[2][start:] == mean) and torch.all(b[2][start:] == mean)
+        if epoch > 1:
+            assert torch.all(a[2][:tail] == 100.0 * epoch + 10.0 * i0)
+            assert torch.all(b[2][:tail] == 100.0 * epoch + 10.0 * (i0 + 1) + 1)
+
+
+def test_dp_nan_on_one_rank_raises_on_every_rank_gloo(tmp_path):
+    world, port = 2, 35000 + os.getpid() % 2000
+    # batch 3 belongs to rank 1 only; epoch 2 is already in phase 2
+    _spawn_with_deadline(_epoch_loop_worker, (world, port, str(tmp_path), (2, 3)), world)
+    r = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
+    assert r[0]['raised'] == 2 and r[1]['raised'] == 2
+    assert len(r[0]['log']) == len(r[1]['log']) == 4            # epoch 1 + the first step of epoch 2
+
+
+def test_nan_restart_loop(tmp_path):
+    """train.py:510-531: restart (fresh try, output wiped) on a NaN in epoch 1, at most 10
+    times; a NaN in a later epoch propagates."""
+    from tracevae_amd.train import NANLossError, run_with_nan_restart
+    out = tmp_path / 'results'
+    calls, messages = [], []
+
+    def job_factory(failures, epoch):
+        def job():
+            calls.append(1)
+            (out / 'models').mkdir(parents=True, exist_ok=True)
+            (out / 'models' / f'{len(calls)}.pt').write_text('x')
+            (out / 'result' / 'test-anomaly').mkdir(parents=True, exist_ok=True)
+            (out / 'config.json').write_text('{}')
+            if len(calls) <= failures:
+                raise NANLossError(epoch)
+            return {'ok': len(calls)}
+        return job
+
+    assert run_with_nan_restart(job_factory(2, 1), str(out), log=messages.append) == {'ok': 3}
+    assert len(messages) == 2 and '2-th time' in messages[1]
+    # only the successful try's files are left; config.json is not wiped
+    assert sorted(os.listdir(out / 'models')) == ['3.pt'] and (out / 'config.json').exists()
+    del calls[:]
+    with pytest.raises(NANLossError) as e:
+        run_with_nan_restart(job_factory(1, 2), str(out), log=messages.append)
+    assert e.value.epoch == 2 and len(calls) == 1
+    del calls[:]
+    with pytest.raises(NANLossError):
+        run_with_nan_restart(job_factory(99, 1), str(out), log=messages.append)
+    assert len(calls) == 11                                    # the first try + 10 restarts

@@ -59,18 +59,10 @@ def test_graph_vectors_match_reference(golden):
 def test_sample_dataset_batching_oracle(golden):
     """a2-a6 on the reference's sample traces: structure of the batched encoder / decoder
     graphs and the observed tensors."""
-    from tracevae_amd.data import FlatTraces, TraceGraphLatencyRangeFile
-    graphs = [g for entry in golden['sets'].values() for g in entry['graphs']]
-    off = np.zeros(len(graphs) + 1, dtype=np.int64)
-    np.cumsum([g['node_count'] for g in graphs], out=off[1:])
-    cat = lambda k, dt: np.concatenate([np.asarray(g[k], dtype=dt) for g in graphs])
-    flat = FlatTraces(node_offsets=off, u=cat('u', np.int64), v=cat('v', np.int64),
-                      node_type=cat('node_type', np.int64),
-                      avg_latency=cat('avg_latency', np.float32),
-                      max_latency=cat('max_latency', np.float32),
-                      min_latency=cat('min_latency', np.float32))
+    from helpers import golden_sample_flat
+    flat, lr, _, graphs = golden_sample_flat()
+    off = flat.node_offsets
     flat.validate(32)
-    lr = TraceGraphLatencyRangeFile(latency_data={int(k): v for k, v in golden['latency_range'].items()})
     b = oracle_batch(flat, lr, golden['num_operations'], 32)
     n, B, M = int(off[-1]), len(graphs), 32
     assert len(b['enc_src']) == 3 * n - 2 * B

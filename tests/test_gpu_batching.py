@@ -47,6 +47,30 @@ def test_synthetic_batches(device):
     _compare(flat, lr, 200, 32, ids)
 
 
+def test_reference_sample_dataset_traces(device):
+    """The 17 traces of the reference's sample data set (arrays from the reference's own
+    graph_vectors(), tests/golden) through tv_batch_build, MAX_NODE_COUNT = 32 and the data
+    set's 1488 operations: bit-equal to the oracle, plus the structure facts the CPU suite
+    checks on the oracle side (edge counts, one in-edge per padded slot, the normalisation)."""
+    from helpers import golden_sample_flat
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    flat, lr, V, graphs = golden_sample_flat()
+    assert len(graphs) == 17 and V == 1488
+    _compare(flat, lr, V, 32)
+    _compare(flat, lr, V, 32, ids=[16, 3, 3, 15, 0])
+    db = TraceGraphBatch.from_store(DeviceTraceStore(flat, lr, V), np.arange(17), 32).build_dgl()
+    n, B, M = int(flat.node_offsets[-1]), 17, 32
+    assert db.enc.num_edges == 3 * n - 2 * B and db.dec.num_edges == B * M + 2 * (n - B)
+    assert db.adj.shape == (B, 496) and float(db.adj.sum()) == n - B
+    assert db.node_count.cpu().tolist() == [g['node_count'] for g in graphs]
+    deg = np.diff(db.dec.indptr.cpu().numpy()).reshape(B, M)
+    for i, g in enumerate(graphs):
+        assert np.all(deg[i, g['node_count']:] == 1)
+    mu, sd = lr[int(flat.node_type[0])]
+    want = np.float32((np.float64(flat.avg_latency[0]) - mu) / (sd + 1e-5))
+    assert db.latency.cpu().numpy()[0, 0] == want
+
+
 def test_edge_topologies(device):
     M = 12
     shapes = [

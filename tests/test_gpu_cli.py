@@ -72,22 +72,28 @@ def test_preprocess_train_test_on_the_sample_dataset(device, tmp_path, capsys):
     assert saved['nll_list'].shape == (n_test,) and np.isfinite(saved['nll_list']).all()
     assert sorted(set(saved['label_list'].tolist())) == [0, 1, 2]
 
-    # the same command sharded over two ranks (gloo rehearsal of the RCCL job on one GPU):
-    # every trace gets the same score, in the same order
+    # the same command sharded over two ranks (gloo rehearsal of the RCCL job on one GPU) with
+    # the noise of every batch seeded by its position in the stream: every trace gets the same
+    # score - bit for bit, the same kernels run on the same batches - in the same order
     import subprocess
     import sys
     nll2 = str(tmp_path / 'nll2.npz')
     env = dict(os.environ, TRACEVAE_DIST_BACKEND='gloo', PYTHONPATH=os.pathsep.join(sys.path))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
            '--master-addr', '127.0.0.1', '--master-port', '29533', '-m', 'tracevae_amd.test',
-           'evaluate-nll', '-M', out, '-D', root, '--batch-size', '3', '--n_z', '1',
-           '--no-latency-biased', '--no-biased', '-o', nll2]
+           'evaluate-nll', '-M', out, '-D', root, '--batch-size', '3', '--n_z', '4',
+           '--noise-seed', '5', '-o', nll2]
     single = str(tmp_path / 'nll1.npz')
-    assert test_cli.main(['evaluate-nll', '-M', out, '-D', root, '--batch-size', '3', '--n_z', '1',
-                          '--no-latency-biased', '--no-biased', '-o', single]) == 0
+    assert test_cli.main(['evaluate-nll', '-M', out, '-D', root, '--batch-size', '3', '--n_z', '4',
+                          '--noise-seed', '5', '-o', single]) == 0
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr[-2000:]
     a, b = np.load(single), np.load(nll2)
     assert np.array_equal(a['label_list'], b['label_list'])
-    assert a['nll_list'].shape == b['nll_list'].shape
+    assert a['nll_list'].shape == (n_test,) and np.array_equal(a['nll_list'], b['nll_list'])
+    # and another seed gives other scores (the seed is what pins them)
+    other = str(tmp_path / 'nll3.npz')
+    assert test_cli.main(['evaluate-nll', '-M', out, '-D', root, '--batch-size', '3', '--n_z', '4',
+                          '--noise-seed', '6', '-o', other]) == 0
+    assert not np.array_equal(np.load(other)['nll_list'], a['nll_list'])

@@ -89,3 +89,88 @@ def test_two_rank_step_equals_averaged_gradients(device, tmp_path):
     assert not torch.allclose(grads[0], grads[1])
     assert any(not torch.equal(got[0]['buffers'][k], got[1]['buffers'][k])
                for k in got[0]['buffers'] if k.endswith('running_mean'))
+
+
+# ---------------------------------------------------------------------------------------
+# the whole data-parallel job: odd batch count, phase switch, sharded evaluation
+# ---------------------------------------------------------------------------------------
+FIT_TRAIN, FIT_VAL, FIT_TEST, FIT_BATCH = 11, 5, 7, 4      # ceil(11 / 4) = 3 batches: 3 % 2 == 1
+
+
+def _fit_config():
+    cfg = make_config(width=WIDTH, layers=LAYERS)
+    cfg.seed = 1234
+    tc = cfg.train
+    tc.max_epoch, tc.struct_pretrain_epochs = 3, 1
+    tc.batch_size = tc.val_batch_size = FIT_BATCH
+    tc.init_batch_size = 8
+    tc.val_epoch_freq, tc.test_epoch_freq, tc.test_n_z = 1, 2, 2
+    cfg.test.batch_size, cfg.test.eval_n_z = 3, 2
+    return cfg
+
+
+def _fit_stores():
+    from tracevae_amd.batch import DeviceTraceStore
+    _, lr = make_flat(4, V, M, seed=40)
+    out = {}
+    for name, n, seed, ratio in (('train', FIT_TRAIN, 41, 0.0), ('val', FIT_VAL, 42, 0.0),
+                                 ('test', FIT_TEST, 43, 0.5)):
+        flat, _ = make_flat(n, V, M, seed=seed, anomaly_ratio=ratio)
+        out[name] = DeviceTraceStore(flat, lr, V)
+    return out
+
+
+def _fit_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from tracevae_amd.train import fit
+    lines = []
+    result = fit(_fit_config(), _fit_stores(), V, os.path.join(tmp, 'out'), rank=rank,
+                 world_size=world, log=lines.append)
+    vae = result.pop('_vae')
+    torch.save({'state': {k: v.cpu() for k, v in vae.state_dict().items()},
+                'nll': result.pop('_nll_list'), 'labels': result.pop('_label_list'),
+                'result': result, 'log': lines}, os.path.join(tmp, f'fit_r{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fit_with_odd_batch_count_across_the_phase_switch(device, tmp_path):
+    """`fit()` with two ranks (gloo, both on the one GPU): 3 batches per epoch for 2 ranks - the
+    case in which the ranks used to run different numbers of all-reduces -, three epochs across
+    the phase-1 -> phase-2 switch, validation and test scoring sharded over the ranks."""
+    import json
+    import time
+    import torch.multiprocessing as mp
+    world, port = 2, 37000 + os.getpid() % 2000
+    ctx = mp.spawn(_fit_worker, args=(world, port, str(tmp_path)), nprocs=world, join=False)
+    deadline = time.time() + 240
+    while not ctx.join(timeout=1.0):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+            pytest.fail('a rank was still blocked at the deadline (unmatched collective?)')
+    r = [torch.load(tmp_path / f'fit_r{i}.pt', weights_only=False) for i in range(world)]
+    # same parameters AND (after the epoch-end averaging) the same BatchNorm buffers everywhere
+    for k, v in r[0]['state'].items():
+        assert torch.equal(v, r[1]['state'][k]), k
+    # every test trace is scored exactly once, labels in stream order, same summary on all ranks
+    want_labels = _fit_stores()['test'].labels
+    for i in range(world):
+        assert r[i]['nll'].shape == (FIT_TEST,) and np.isfinite(r[i]['nll']).all()
+        assert np.array_equal(r[i]['labels'], want_labels)
+    assert np.array_equal(r[0]['nll'], r[1]['nll'])
+    assert r[0]['result'] == r[1]['result'] or all(
+        (a == b) or (a != a and b != b) for a, b in zip(r[0]['result'].values(), r[1]['result'].values()))
+    assert np.isfinite(r[0]['result']['val_loss'])
+    out = tmp_path / 'out'
+    for f in ('config.json', 'models/1.pt', 'models/3.pt', 'models/final.pt',
+              'result/test-anomaly/2.json', 'result/test-anomaly/final.json'):
+        assert (out / f).exists(), f
+    assert any('Start to train latency_vae' in line for line in r[0]['log'])
+    with open(out / 'result' / 'test-anomaly' / 'final.json') as f:
+        assert json.load(f).keys() >= {'auc', 'best_fscore', 'test_loss'}

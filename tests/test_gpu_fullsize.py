@@ -3,7 +3,7 @@ default TraceVAE dims, MAX_NODE_COUNT=100; configs[4]: 500 spans, 10k operations
 widths).  The oracle does not finish these in seconds, so parity is carried by the small-size
 tests and these check size-independent properties of the HIP path: bit-equal reruns, scores
 that do not depend on how the traces are batched, K-sample scores that equal the scores of
-their replicas, a loss that goes down, and data-parallel gradient averaging."""
+their replicas (K = 4 and K = 100), and a loss that goes down."""
 import numpy as np
 import pytest
 import torch
@@ -93,31 +93,26 @@ def test_scores_independent_of_batching_and_of_k_replication(full, device):
     assert torch.equal(nll, again)
 
 
-def test_data_parallel_gradient_is_the_mean_of_shard_gradients(full, device):
-    """What the RCCL all-reduce (ReduceOp.AVG over the flat gradient bucket) must produce on 2
-    GPUs: computed here on one GPU by running the two shards in turn."""
+def test_k100_score_is_the_log_mean_exp_of_its_100_replicas(full, device):
+    """BASELINE configs[3]: K = 100 samples per trace in ONE call (100 block-diagonal replicas
+    of the decoder graphs) equals the log-mean-exp of 100 single-sample calls."""
     from tracevae_amd.batch import TraceGraphBatch
-    from tracevae_amd.train import Trainer
+    from tracevae_amd.evaluation import eval_step
     cfg, vae, store = full
-    vae.train()
-    trainer = Trainer(vae, cfg, world_size=1)
-    shard_grads = []
-    for r in range(2):
-        ids = np.arange(r * 64, (r + 1) * 64)
-        trainer.flat.zero_grad()
-        out = trainer.forward_loss(TraceGraphBatch.from_store(store, ids, M), eps=_eps((64,), 50 + r))
-        out['loss'].backward()
-        shard_grads.append(trainer.flat.grad.clone())
-    mean = (shard_grads[0] + shard_grads[1]) / 2
-    assert torch.isfinite(mean).all() and float(mean.abs().max()) > 0
-    # the same thing through the trainer's bucket path with a two-rank gloo group is covered on
-    # the CPU (tests/test_cpu_host.py); here: the bucket is one contiguous buffer that holds
-    # every parameter gradient exactly once
-    total = sum(p.numel() for p in vae.parameters())
-    assert trainer.flat.grad.numel() >= total
-    views = sum(int(p.grad.data_ptr() >= trainer.flat.grad.data_ptr()) for p in vae.parameters()
-                if p.grad is not None)
-    assert views == sum(1 for p in vae.parameters() if p.grad is not None)
+    vae.eval()
+    K, n = 100, 8
+    eps = _eps((K, n), 11)
+    kw = dict(use_biased=True, use_latency_biased=True, latency_log_prob_weight=True)
+    G = lambda: TraceGraphBatch.from_store(store, np.arange(40, 40 + n), M)
+    loss, nll = eval_step(vae, G(), K, eps=eps, clip_nll=None, **kw)
+    assert torch.isfinite(nll).all() and torch.isfinite(loss).all()
+    singles = [eval_step(vae, G(), 1, eps={name: v[k:k + 1] for name, v in eps.items()},
+                         clip_nll=None, **kw)[1] for k in range(K)]
+    w = -torch.stack(singles).double()                 # log importance weights [K, n]
+    assert rel_err(nll, -(torch.logsumexp(w, 0) - np.log(K))) < 1e-5
+    assert rel_err(loss, -w.mean(0)) < 1e-5
+    _, again = eval_step(vae, G(), K, eps=eps, clip_nll=None, **kw)
+    assert torch.equal(nll, again)
 
 
 def test_long_trace_configuration_runs(device):

@@ -106,7 +106,9 @@ def test_train_step_loss_and_gradients(device, V, M, width, layers, batch):
 
 @pytest.mark.parametrize('use_flow,dims', [(True, (80, 20, 24, 2, 11, 5)), (False, (80, 20, 24, 2, 11, 5)),
                                            # BASELINE configs[1] / [3] dims
-                                           (True, (1001, 100, None, None, 12, 3))])
+                                           (True, (1001, 100, None, None, 12, 3)),
+                                           # configs[3] as stated: K = 100 samples per trace
+                                           (True, (1001, 100, None, None, 4, 100))])
 def test_eval_step_scores(device, use_flow, dims):
     from oracle.model import OracleTraceVAE
     from tracevae_amd.batch import TraceGraphBatch
@@ -150,6 +152,40 @@ def test_eval_step_scores(device, use_flow, dims):
     _, n1 = eval_step(vae, TraceGraphBatch.from_store(store, np.arange(half), M), K, eps=e1, **kw)
     _, n2 = eval_step(vae, TraceGraphBatch.from_store(store, np.arange(half, B), M), K, eps=e2, **kw)
     assert rel_err(torch.cat([n1, n2]), nll) < 1e-5
+
+
+def test_eval_step_long_trace_configuration(device):
+    """BASELINE configs[4] dims against the fp64 oracle: 500-span traces (M = 500, 124 750 node
+    pairs), 10k-operation vocabulary, z = z2 = 20, 2 x 1000 GAT stacks, doubled MLP widths and
+    latent_embedding_size = 80.  B = 2, K = 1."""
+    from oracle.model import OracleTraceVAE
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.evaluation import eval_step
+    V, M, nb, K = 10001, 500, 2, 1
+    extra = ('--model.struct.z_dim=20', '--model.latency.z2_dim=20',
+             '--model.struct.decoder.latent_embedding_size=80',
+             '--model.struct.decoder.node_count_layers=[1000]',
+             '--model.struct.decoder.graph_embedding_layers=[1000,1000]',
+             '--model.latency.decoder.z2_given_z_hidden_layers=[500,500]')
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 1000, 4, nb, seed=5,
+                                                       extra=extra)
+    assert int(flat.node_counts.max()) > 100          # long traces, not the configs[1] ones
+    vae.eval()
+    g = torch.Generator().manual_seed(2)
+    eps_z, eps_z2 = torch.randn(K, nb, 20, generator=g), torch.randn(K, nb, 20, generator=g)
+    orc = OracleTraceVAE(cfg.model, V, M, dtype=torch.float64)
+    ob = oracle_batch(flat, lr, V, M)
+    ref = orc.eval_step(P, buf, ob, eps_z.double(), eps_z2.double(), use_biased=True,
+                        use_latency_biased=True, latency_log_prob_weight=True, clip_nll=1e12)
+    G = TraceGraphBatch.from_store(store, np.arange(nb), M)
+    loss, nll, chain = eval_step(vae, G, K, use_biased=True, use_latency_biased=True,
+                                 latency_log_prob_weight=True, clip_nll=1e12,
+                                 eps={'z': eps_z, 'z2': eps_z2}, return_chain=True)
+    assert rel_err(nll, ref['nll']) < PATH_TOL and rel_err(loss, ref['loss']) < PATH_TOL
+    for name, key in (('z', 'log_p_z'), ('node_count', 'log_p_node_count'), ('adj', 'log_p_adj'),
+                      ('node_type', 'log_p_node_type'), ('z2', 'log_p_z2'),
+                      ('latency', 'log_p_latency')):
+        assert rel_err(chain.p[name].log_prob(), ref['p'][key]) < PATH_TOL, name
 
 
 def test_eval_step_no_struct_scores_the_latency_model_alone(device):

@@ -465,7 +465,10 @@ def test_latency_ll_compact_rows(device, mode):
 
 # -------------------------------------------------------------------------- likelihoods
 @pytest.mark.parametrize('M,D,K,biased', [(16, 40, 1, False), (16, 40, 3, True), (100, 40, 2, True),
-                                          (70, 80, 1, False)])
+                                          (70, 80, 1, False), (33, 40, 2, True), (129, 24, 1, True),
+                                          # BASELINE configs[4]: 500-span traces, doubled
+                                          # latent_embedding_size (124 750 node pairs per trace)
+                                          (500, 80, 2, True), (500, 80, 1, False)])
 def test_adj_bernoulli_ll(device, M, D, K, biased):
     from oracle.model import bernoulli_log_prob, biased as biased_fn, dense_to_triu
     from tracevae_amd import ops
@@ -488,7 +491,8 @@ def test_adj_bernoulli_ll(device, M, D, K, biased):
     assert rel_err(hd.grad, hr.grad) < 5 * TOL
 
 
-@pytest.mark.parametrize('V,biased', [(1001, False), (33, True), (1488, False)])
+@pytest.mark.parametrize('V,biased', [(1001, False), (33, True), (1488, False),
+                                      (10001, False)])       # configs[4]: 10k-operation vocabulary
 def test_categorical_ll(device, V, biased):
     from oracle.model import biased as biased_fn, categorical_log_prob
     from tracevae_amd import ops

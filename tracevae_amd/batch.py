@@ -217,7 +217,7 @@ class TraceGraphBatch(object):
     `dgl_batch` slots of the reference hold DGL objects; here `dgl_batch` holds the
     `DeviceBatch` (same role: the batched device-side graph + node data)."""
     __slots__ = ['id_manager', 'latency_range', 'trace_graphs', 'dgl_graphs', 'dgl_batch',
-                 '_store', '_trace_ids', '_max_node_count']
+                 '_store', '_trace_ids', '_max_node_count', '_stream_index']
 
     def __init__(self, *, id_manager: Optional[TraceGraphIDManager] = None,
                  latency_range: Optional[TraceGraphLatencyRangeFile] = None,
@@ -235,6 +235,7 @@ class TraceGraphBatch(object):
         self._store = None
         self._trace_ids = None
         self._max_node_count = None
+        self._stream_index = None
         if trace_graphs is not None and dgl_batch is None:
             v = num_operations if num_operations is not None else id_manager.num_operations
             if latency_range is None:
@@ -255,6 +256,7 @@ class TraceGraphBatch(object):
         self._store = store
         self._trace_ids = np.asarray(trace_ids, dtype=np.int64)
         self._max_node_count = max_node_count
+        self._stream_index = None      # position in its StoreStream (seeds reproducible noise)
         return self
 
     def build_dgl(self, add_self_loop: bool = True, directed: Union[bool, str] = False,

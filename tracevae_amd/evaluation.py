@@ -182,7 +182,8 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
                     latency_reldiff_dict_out: Optional[DeviceCollector] = None,
                     p_node_count_dict_out: Optional[DeviceCollector] = None,
                     p_edge_dict_out: Optional[DeviceCollector] = None,
-                    process_group=None, **_ignored) -> Dict[str, float]:
+                    process_group=None, noise_seed: Optional[int] = None,
+                    **_ignored) -> Dict[str, float]:
     """The scoring driver (evaluation.py:40-283): score every batch of the stream, keep scores
     and collected per-node values on the GPU until the end (one device->host copy each), then
     the summary of `analyze_anomaly_nll` and the optional `.npz` (`nll_list`, `label_list`,
@@ -191,7 +192,11 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
     std and |latency - mean| / std of every real node, by trace label); `p_node_count_dict_out`
     gathers p(node_count = observed) and `p_edge_dict_out` the |(1 - adj) - p(edge)| entries of
     every trace's dense n x n block, both of sample 0 (tensor_utils.py:171-198).  The
-    plotting / TensorBoard arguments of the reference are accepted and ignored."""
+    plotting / TensorBoard arguments of the reference are accepted and ignored.
+
+    `noise_seed` (an extension): the N(0,1) draws of batch i of the stream come from a CPU
+    generator seeded with (noise_seed, i), so the scores do not depend on how the stream is
+    sharded over ranks; by default the device generator draws them."""
     was_training = vae.training
     vae.eval()
     nll_chunks: List[torch.Tensor] = []
@@ -207,13 +212,21 @@ def do_evaluate_nll(test_stream: Iterable[TraceGraphBatch], vae: TraceVAE, n_z: 
     collect = collect_lat or collect_struct
     offset = 0
     try:
-        for G in test_stream:
+        for step_index, G in enumerate(test_stream):
+            eps = None
+            if noise_seed is not None:
+                index = getattr(G, '_stream_index', None)
+                gen = torch.Generator().manual_seed(
+                    int(noise_seed) * 1000003 + int(step_index if index is None else index))
+                eps = {'z': torch.randn(n_z, len(G), vae.config.struct.z_dim, generator=gen)}
+                if vae.config.use_latency and not no_latency:
+                    eps['z2'] = torch.randn(n_z, len(G), vae.config.latency.z2_dim, generator=gen)
             res = eval_step(
                 vae, G, n_z, use_biased=use_biased, use_latency_biased=use_latency_biased,
                 no_latency=no_latency, std_limit=std_limit,
                 latency_log_prob_weight=latency_log_prob_weight,
                 latency_logstd_min=latency_logstd_min, clip_nll=clip_nll, return_chain=collect,
-                no_struct=no_struct)
+                no_struct=no_struct, eps=eps)
             loss, nll = res[0], res[1]
             nll_chunks.append(nll)
             loss_chunks.append(loss.mean().reshape(1))

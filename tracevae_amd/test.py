@@ -87,7 +87,8 @@ def evaluate_nll(vae: TraceVAE, test_stream: Iterable[TraceGraphBatch],
                  threshold_amplify: float = 1.0, no_latency_log_prob_weight: bool = False,
                  use_std_limit: bool = False, std_limit_global: bool = False,
                  std_limit_fixed: Optional[float] = None, std_limit_p: float = 0.99,
-                 std_limit_amplify: float = 1.0, rng=None, process_group=None) -> Dict[str, float]:
+                 std_limit_amplify: float = 1.0, rng=None, process_group=None,
+                 noise_seed: Optional[int] = None) -> Dict[str, float]:
     """`evaluate_nll` of test.py with its option names (the `infer_*` flags carry a trailing
     underscore here because the functions above own the plain names).  Returns the merged
     result dict: `train_*` / `val_*` / `test_*` metrics, `bias_std`, `train_threshold`,
@@ -112,7 +113,8 @@ def evaluate_nll(vae: TraceVAE, test_stream: Iterable[TraceGraphBatch],
             latency_log_prob_weight=not no_latency_log_prob_weight, std_limit=std_limit,
             test_threshold=threshold, clip_nll=clip_nll, nll_output_file=out_file,
             operation_id_dict_out=operation_id, latency_std_dict_out=latency_std,
-            latency_reldiff_dict_out=latency_reldiff, process_group=process_group)
+            latency_reldiff_dict_out=latency_reldiff, process_group=process_group,
+            noise_seed=noise_seed)
         nll_result[category] = r.pop('_nll_list')
         r.pop('_label_list')
         results.update({f'{category}_{key}': v for key, v in r.items()})
@@ -170,16 +172,17 @@ def main(argv=None) -> int:
     p.add_argument('--std-limit-fixed', type=float, default=None)
     p.add_argument('--std-limit-p', type=float, default=0.99)
     p.add_argument('--std-limit-amplify', type=float, default=1.0)
+    p.add_argument('--noise-seed', type=int, default=None,
+                   help='(extension) seed the N(0,1) draws per batch of the stream, so that the '
+                        'scores do not depend on the number of ranks')
     args, extra = ap.parse_known_args(argv)
     if not torch.cuda.is_available():
         from . import hip
         raise hip.HipLibraryError('the accelerated path needs a GPU (there is no CPU fallback); '
                                   f'--device={args.device} cannot be honoured')
     import torch.distributed as dist
-    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
-    if world > 1:      # sharded scoring: rank r takes batches r, r+W, ...
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
-        dist.init_process_group(os.environ.get('TRACEVAE_DIST_BACKEND', 'nccl'))
+    from .train import init_distributed
+    rank, world = init_distributed()     # sharded scoring: rank r takes batches r, r+W, ...
     device = torch.device('cuda', torch.cuda.current_device())
     # the data set root comes from the train config unless -D is given (test.py:108-109)
     cfg_dir = os.path.dirname(os.path.dirname(os.path.abspath(args.model_path))) \
@@ -208,7 +211,8 @@ def main(argv=None) -> int:
         use_std_limit=args.use_std_limit, std_limit_global=args.std_limit_global,
         std_limit_fixed=args.std_limit_fixed, std_limit_p=args.std_limit_p,
         std_limit_amplify=args.std_limit_amplify,
-        rng=np.random.RandomState(0) if world > 1 else None)   # same bootstrap on every rank
+        rng=np.random.RandomState(0) if world > 1 else None,   # same bootstrap on every rank
+        noise_seed=args.noise_seed)
     limit = result.pop('std_limit')
     if limit is not None:
         result['std_limit_max'] = float(limit.max())

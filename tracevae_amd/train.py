@@ -36,7 +36,8 @@ FUSED_TRAIN_LOSS = os.environ.get('TRACEVAE_FUSED_LOSS', '1') != '0'
 
 __all__ = ['NANLossError', 'FlatParameters', 'FlatOptimizer', 'compute_train_loss', 'Trainer',
            'l2_parameter_names', 'learning_rate_for_epoch', 'save_model', 'StoreStream', 'fit',
-           'load_model', 'main']
+           'run_training', 'run_with_nan_restart', 'init_distributed', 'all_reduce_sum',
+           'broadcast_model', 'average_batch_norm_buffers', 'load_model', 'main']
 
 
 class NANLossError(Exception):
@@ -83,7 +84,12 @@ class FlatParameters(object):
             cur += (s + 63) // 64 * 64
         self.total = cur
         self.flat = torch.zeros(cur, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(cur, dtype=torch.float32, device=device)
+        # the gradient bucket carries one more (256-B aligned) slot behind the gradients: the
+        # NaN flag of the step, so that ONE all-reduce moves both and every rank takes the same
+        # NaN decision (Trainer.exchange)
+        self.bucket = torch.zeros(cur + 64, dtype=torch.float32, device=device)
+        self.grad = self.bucket[:cur]
+        self.flag_index = cur
         self.names = [n for n, _ in ordered]
         self.slices: Dict[str, Tuple[int, int]] = {}
         self.tail_start = cur
@@ -296,7 +302,9 @@ class Trainer(object):
         out['chain'] = chain
         return out
 
-    def step(self, G: TraceGraphBatch, eps=None, check_nan: bool = True) -> Dict[str, torch.Tensor]:
+    def local_gradients(self, G: TraceGraphBatch, eps=None) -> Dict[str, torch.Tensor]:
+        """Forward + backward of this rank's mini-batch; the gradient of the loss (L2 term
+        included) ends up in the flat bucket."""
         f = self.flat
         f.begin_backward()
         out = self.forward_loss(G, eps)
@@ -306,34 +314,114 @@ class Trainer(object):
             # d(l2_reg * sum p^2)/dp = 2 * l2_reg * p on the masked elements
             hip.call('tv_axpy_masked', f.total, 2.0 * self.train_cfg.l2_reg, hip.ptr(f.flat),
                      hip.ptr(self.l2_mask), hip.ptr(f.grad))
-        self.all_reduce_gradients()
-        if check_nan:
-            loss_val = float(out['loss'].item())          # host sync, like train.py:273
-            if math.isnan(loss_val):
-                raise NANLossError(self.epoch)
+        return out
+
+    def update(self) -> None:
+        """Clip by global norm + RMSprop / Adam over the trained range of the flat buffer."""
         self.optimizer.step(self.train_cfg.global_clip_norm)
+
+    def step(self, G: TraceGraphBatch, eps=None, check_nan: bool = True) -> Dict[str, torch.Tensor]:
+        """One training step.  With several ranks every rank makes exactly the same sequence of
+        collectives (one all-reduce per step) and takes the same NaN decision, so a NaN on one
+        rank raises `NANLossError` on all of them instead of leaving the others blocked."""
+        out = self.local_gradients(G, eps)
+        self.exchange(out['loss'])
+        if check_nan and self.loss_is_nan(out['loss']):     # host sync, like train.py:273
+            raise NANLossError(self.epoch)
+        self.update()
         return {k: v.detach() for k, v in out.items() if k != 'chain'}
 
-    def all_reduce_gradients(self) -> None:
-        """One collective over the flat gradient bucket: sum over ranks, divide by world."""
+    def loss_is_nan(self, loss: torch.Tensor) -> bool:
+        if self.world_size > 1:
+            # the all-reduced flag: the number of ranks whose loss was NaN
+            return float(self.flat.bucket[self.flat.flag_index].item()) != 0.0
+        return math.isnan(float(loss.item()))
+
+    def exchange(self, loss: Optional[torch.Tensor] = None) -> None:
+        """One collective over [gradients of the trained range | NaN flag]: sum over ranks,
+        gradients divided by the world size."""
         if self.world_size <= 1:
             return
-        g = self.flat.grad[self.optimizer.start:self.optimizer.end]
-        backend = dist.get_backend(self.pg)
-        if backend == 'nccl':   # RCCL over xGMI
-            # SUM then scale (one 25 us pass over the bucket) instead of ReduceOp.AVG: the sum
-            # is the one reduction every RCCL build has, and this path cannot be rehearsed on
-            # the one-GPU development box
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
-            g.mul_(1.0 / self.world_size)
+        f = self.flat
+        flag = f.bucket[f.flag_index:f.flag_index + 1]
+        if loss is None:
+            flag.zero_()
         else:
-            # gloo (CPU tests, rehearsals): stage through the host, gloo's device path is not
-            # dependable on ROCm
-            h = g.detach().cpu() if g.is_cuda else g
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
-            h.div_(self.world_size)
-            if g.is_cuda:
-                g.copy_(h)
+            flag.copy_(torch.isnan(loss.detach()).reshape(1))
+        g = f.bucket[self.optimizer.start:f.flag_index + 1]
+        all_reduce_sum(g, self.pg)
+        # SUM then scale (one 25 us pass over the bucket) instead of ReduceOp.AVG: the sum is
+        # the one reduction every RCCL build has
+        f.grad[self.optimizer.start:self.optimizer.end].mul_(1.0 / self.world_size)
+
+    def all_reduce_gradients(self) -> None:
+        self.exchange(None)
+
+
+def _uses_device_collectives(group) -> bool:
+    return dist.get_backend(group) == 'nccl'      # RCCL over xGMI
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> None:
+    """In-place sum over the ranks.  RCCL reduces device memory directly; under gloo (CPU
+    tests, rehearsals with more ranks than GPUs) device tensors are staged through the host:
+    gloo's device path is not dependable on ROCm."""
+    if _uses_device_collectives(group) or not t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    h = t.detach().cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(h)
+
+
+def broadcast_from_rank0(t: torch.Tensor, group=None) -> None:
+    if _uses_device_collectives(group) or not t.is_cuda:
+        dist.broadcast(t, 0, group=group)
+        return
+    h = t.detach().cpu()
+    dist.broadcast(h, 0, group=group)
+    t.copy_(h)
+
+
+def _float_buffers(module: torch.nn.Module) -> List[torch.Tensor]:
+    seen, out = set(), []
+    for b in module.buffers():
+        if b.dtype.is_floating_point and b.data_ptr() not in seen:
+            seen.add(b.data_ptr())
+            out.append(b)
+    return out
+
+
+def broadcast_model(trainer: 'Trainer', group=None) -> None:
+    """Rank 0's parameters (one flat buffer) and floating-point buffers to every rank."""
+    broadcast_from_rank0(trainer.flat.flat, group)
+    bufs = _float_buffers(trainer.vae)
+    if bufs:
+        packed = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+        broadcast_from_rank0(packed, group)
+        off = 0
+        for b in bufs:
+            b.copy_(packed[off:off + b.numel()].view(b.shape))
+            off += b.numel()
+
+
+def average_batch_norm_buffers(module: torch.nn.Module, world_size: int, group=None) -> None:
+    """BatchNorm batch statistics are per rank during training (no SyncBN); before a model is
+    scored or saved the running means / variances are averaged over the ranks, so that every
+    rank scores with - and rank 0 saves - the same buffers.  One small all-reduce."""
+    if world_size <= 1:
+        return
+    bufs = _float_buffers(module)
+    if not bufs:
+        return
+    packed = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    all_reduce_sum(packed, group)
+    packed.mul_(1.0 / world_size)
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(packed[off:off + b.numel()].view(b.shape))
+            off += b.numel()
 
 
 def save_model(vae: TraceVAE, config: ExpConfig, out_dir: str, name: str = 'final') -> str:
@@ -349,30 +437,45 @@ def save_model(vae: TraceVAE, config: ExpConfig, out_dir: str, name: str = 'fina
 
 class StoreStream(object):
     """Mini-batches of trace indices over a `DeviceTraceStore` (the role of
-    `TraceGraphDataStream`, dataset.py:92-133); rank r of W takes batches r, r+W, ..."""
+    `TraceGraphDataStream`, dataset.py:92-133); rank r of W takes batches r, r+W, ...
+
+    `equal_steps` (the training stream of a data-parallel job): every rank must run the same
+    number of steps per epoch, because every step is one all-reduce.  The tail rule: an epoch
+    uses the first `total - total % W` batches of its permutation, the up to W-1 batches left
+    over are dropped for that epoch (the next epoch's permutation picks them up again)."""
 
     def __init__(self, store: DeviceTraceStore, batch_size: int, shuffle: bool = False,
                  seed: int = 0, rank: int = 0, world_size: int = 1,
-                 max_node_count: Optional[int] = None, skip_incomplete: bool = False):
+                 max_node_count: Optional[int] = None, skip_incomplete: bool = False,
+                 equal_steps: bool = False):
         self.store, self.batch_size, self.shuffle = store, batch_size, shuffle
         self.rng = np.random.RandomState(seed)
         self.rank, self.world_size = rank, world_size
         self.max_node_count = max_node_count
         self.skip_incomplete = skip_incomplete
+        self.equal_steps = equal_steps
+
+    @property
+    def total_batches(self) -> int:
+        """Batches per epoch over all ranks."""
+        n = len(self.store)
+        total = n // self.batch_size if self.skip_incomplete else -(-n // self.batch_size)
+        if self.equal_steps:
+            total -= total % self.world_size
+        return total
 
     @property
     def batch_count(self) -> int:
-        n = len(self.store)
-        total = n // self.batch_size if self.skip_incomplete else -(-n // self.batch_size)
-        return len(range(self.rank, total, self.world_size))
+        return len(range(self.rank, self.total_batches, self.world_size))
 
     def __iter__(self):
         n = len(self.store)
         order = self.rng.permutation(n) if self.shuffle else np.arange(n)
-        total = n // self.batch_size if self.skip_incomplete else -(-n // self.batch_size)
-        for i in range(self.rank, total, self.world_size):
+        for i in range(self.rank, self.total_batches, self.world_size):
             ids = order[i * self.batch_size:(i + 1) * self.batch_size]
-            yield TraceGraphBatch.from_store(self.store, ids, self.max_node_count)
+            G = TraceGraphBatch.from_store(self.store, ids, self.max_node_count)
+            G._stream_index = i
+            yield G
 
 
 # ---------------------------------------------------------------------------------------
@@ -400,6 +503,28 @@ def load_model(model_path: str, num_operations: int, extra_args=(), device=None)
     return vae, config
 
 
+def run_training(trainer: 'Trainer', train_stream: Iterable[TraceGraphBatch], train_cfg,
+                 pretrain_epochs: Optional[int] = None, epoch_end=None, log=print) -> None:
+    """The epoch loop of train.py:455-487: epochs 1..pretrain_epochs move every parameter, the
+    rest only `latency_vae.*`; the learning rate is set per epoch; `epoch_end(epoch, mean_loss,
+    seconds)` runs after every epoch on every rank.  Under data parallelism `train_stream` must
+    give every rank the same number of batches (`StoreStream(equal_steps=True)`): each step
+    is one collective."""
+    for epoch in range(1, train_cfg.max_epoch + 1):
+        if pretrain_epochs and epoch == pretrain_epochs + 1:
+            trainer.epoch = epoch
+            trainer.set_phase(latency_only=True)
+            log(f'Start to train latency_vae with {len(trainer.part_names)} params ...')
+        trainer.set_epoch(epoch)
+        trainer.apply_mode()
+        t0, losses = time.perf_counter(), []
+        for G in train_stream:
+            losses.append(trainer.step(G)['loss'])
+        mean_loss = float(torch.stack(losses).mean()) if losses else float('nan')
+        if epoch_end is not None:
+            epoch_end(epoch, mean_loss, time.perf_counter() - t0)
+
+
 def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: int,
         out_dir: str, rank: int = 0, world_size: int = 1, process_group=None,
         log=print) -> Dict[str, float]:
@@ -407,8 +532,14 @@ def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: 
     the rest only `latency_vae.*` with everything else in eval mode (train.py:455-487); the
     learning rate is annealed per epoch; validation, periodic test scoring and a checkpoint
     after every epoch; final K-sample scoring of the test sets and `models/final.pt`.
-    `stores`: 'train', 'val', 'test' (the three test sets concatenated).  With world_size > 1
-    rank r trains on batches r, r+W, ... of every epoch's permutation and rank 0 writes."""
+    `stores`: 'train', 'val', 'test' (the three test sets concatenated).
+
+    With world_size > 1 (one process per GPU): rank r trains on batches r, r+W, ... of every
+    epoch's permutation (equal step counts, see `StoreStream`); weights - including the
+    data-dependent ActNorm initialisation - come from rank 0; every rank draws its own noise
+    (seed + rank); BatchNorm running statistics are averaged over the ranks at the end of
+    every epoch, before validation / test scoring / saving; validation and test traces are
+    sharded over the ranks and the results gathered; rank 0 writes the files."""
     from .evaluation import do_evaluate_nll
     tc = config.train
     if config.seed is not None:
@@ -416,20 +547,20 @@ def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: 
         np.random.seed(config.seed)
     device = stores['train'].device
     vae = TraceVAE(config.model, num_operations).to(device)
-    if world_size > 1:
-        for t in list(vae.parameters()) + list(vae.buffers()):
-            dist.broadcast(t.data, 0, group=process_group)
     trainer = Trainer(vae, config, world_size=world_size, process_group=process_group)
     train_stream = StoreStream(stores['train'], tc.batch_size, shuffle=True,
-                               seed=config.seed or 0, rank=rank, world_size=world_size)
-    val_stream = StoreStream(stores['val'], tc.val_batch_size)
-    test_stream = StoreStream(stores['test'], config.test.batch_size)
+                               seed=config.seed or 0, rank=rank, world_size=world_size,
+                               equal_steps=True)
+    val_stream = StoreStream(stores['val'], tc.val_batch_size, rank=rank, world_size=world_size)
+    test_stream = StoreStream(stores['test'], config.test.batch_size, rank=rank,
+                              world_size=world_size)
     result: Dict[str, float] = {}
 
     def evaluate(n_z, tag):
         r = do_evaluate_nll(test_stream, vae, n_z, use_biased=config.test.use_biased,
                             latency_log_prob_weight=config.test.latency_log_prob_weight,
-                            clip_nll=config.test.clip_nll)
+                            clip_nll=config.test.clip_nll, process_group=process_group)
+        result['_nll_list'], result['_label_list'] = r['_nll_list'], r['_label_list']
         r = {k: v for k, v in r.items() if not k.startswith('_')}
         if rank == 0:
             path = os.path.join(out_dir, 'result', 'test-anomaly', f'{tag}.json')
@@ -437,6 +568,20 @@ def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: 
             with open(path, 'w', encoding='utf-8') as f:
                 f.write(json.dumps(r))
         return r
+
+    def validation_loss() -> float:
+        vae.eval()
+        with torch.no_grad():
+            parts = [(vae.q(G).chain(vae.p, G=G).vi.training.sgvb().mean(), len(G))
+                     for G in val_stream]
+        # batch-size weighted mean over the batches of all ranks
+        acc = torch.zeros(2, dtype=torch.float64, device=device)
+        for v, n in parts:
+            acc[0] += v.double() * n
+            acc[1] += n
+        if world_size > 1:
+            all_reduce_sum(acc, process_group)
+        return float(acc[0] / acc[1]) if float(acc[1]) > 0 else float('nan')
 
     # data-dependent initialisation on one batch (train.py:188-199), in the training mode
     trainer.apply_mode()
@@ -447,25 +592,18 @@ def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: 
         G = TraceGraphBatch.from_store(stores['train'], init_ids)
         loss = vae.q(G).chain(vae.p, G=G).vi.training.sgvb(reduction='mean')
     log(f'Network initialized: loss = {float(loss):.6g}')
+    if world_size > 1:
+        # every rank continues from rank 0's weights and buffers (the ActNorm initialisation
+        # above included), and draws its own noise from here on
+        broadcast_model(trainer, process_group)
+        if config.seed is not None:
+            torch.manual_seed(config.seed + rank)
 
-    pretrain = tc.struct_pretrain_epochs if config.model.arch == 'default' else None
-    for epoch in range(1, tc.max_epoch + 1):
-        if pretrain and epoch == pretrain + 1:
-            trainer.epoch = epoch
-            trainer.set_phase(latency_only=True)
-            log(f'Start to train latency_vae with {len(trainer.part_names)} params ...')
-        trainer.set_epoch(epoch)
-        trainer.apply_mode()
-        t0, losses = time.perf_counter(), []
-        for G in train_stream:
-            losses.append(trainer.step(G)['loss'])
-        mean_loss = float(torch.stack(losses).mean()) if losses else float('nan')
-        msg = f'epoch {epoch}/{tc.max_epoch}: loss {mean_loss:.6g} ({time.perf_counter() - t0:.2f}s)'
+    def epoch_end(epoch, mean_loss, seconds):
+        average_batch_norm_buffers(vae, world_size, process_group)
+        msg = f'epoch {epoch}/{tc.max_epoch}: loss {mean_loss:.6g} ({seconds:.2f}s)'
         if tc.val_epoch_freq and epoch % tc.val_epoch_freq == 0:
-            vae.eval()
-            with torch.no_grad():
-                vals = [vae.q(G).chain(vae.p, G=G).vi.training.sgvb().mean() for G in val_stream]
-            result['val_loss'] = float(torch.stack(vals).mean()) if vals else float('nan')
+            result['val_loss'] = validation_loss()
             msg += f' val_loss {result["val_loss"]:.6g}'
         log(msg)
         if tc.test_epoch_freq and epoch % tc.test_epoch_freq == 0:
@@ -474,12 +612,67 @@ def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: 
                 f'{r.get("best_fscore", float("nan")):.4f}')
         if rank == 0:
             save_model(vae, config, out_dir, name=str(epoch))
+
+    pretrain = tc.struct_pretrain_epochs if config.model.arch == 'default' else None
+    run_training(trainer, train_stream, tc, pretrain, epoch_end, log)
     vae.eval()
     if rank == 0:
         save_model(vae, config, out_dir, name='final')
     result.update(evaluate(config.test.eval_n_z, 'final'))
     result['_vae'] = vae
     return result
+
+
+# directories of an experiment that a restart wipes (train.py:524-529; this package writes
+# the first two, the others are the reference's and are cleared when present)
+RESTART_WIPES = ('models', 'result', 'checkpoint', 'early-stopping', 'plotting', 'summary')
+MAX_NAN_RESTARTS = 10
+
+
+def run_with_nan_restart(job, out_dir: str, rank: int = 0, world_size: int = 1,
+                         process_group=None, log=None):
+    """The outer loop of train.py:510-531: when the loss turns NaN during epoch 1 the whole
+    experiment starts over (a fresh model, up to 10 times), with the output directories of the
+    failed try removed; a NaN in a later epoch, or an eleventh one, propagates.  `job()` runs
+    one try.  Under data parallelism `NANLossError` is raised on every rank in the same step
+    (`Trainer.step`), so all ranks restart together."""
+    import shutil
+    retrial = 0
+    while True:
+        try:
+            return job()
+        except NANLossError as ex:
+            if ex.epoch != 1 or retrial >= MAX_NAN_RESTARTS:
+                raise
+            retrial += 1
+            (log or (lambda m: print(m, file=sys.stderr)))(
+                f'\nRestart the experiment for the {retrial}-th time due to NaN loss at epoch '
+                f'{ex.epoch}.\n')
+            if rank == 0:
+                for name in RESTART_WIPES:
+                    path = os.path.join(out_dir, name)
+                    if os.path.isdir(path):
+                        shutil.rmtree(path)
+            if world_size > 1:
+                dist.barrier(group=process_group)
+
+
+def init_distributed() -> Tuple[int, int]:
+    """(rank, world size) from the torch.distributed.run environment; one process per GPU over
+    RCCL (`TRACEVAE_DIST_BACKEND=gloo` rehearses the control flow on a box with fewer GPUs than
+    ranks)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        index = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
+        torch.cuda.set_device(index)
+        backend = os.environ.get('TRACEVAE_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            # device_id binds the communicator to this rank's GPU up front
+            dist.init_process_group('nccl', device_id=torch.device('cuda', index))
+        else:
+            dist.init_process_group(backend)
+    return rank, world
 
 
 def main(argv=None) -> int:
@@ -499,11 +692,7 @@ def main(argv=None) -> int:
     if not torch.cuda.is_available():
         raise hip.HipLibraryError('the accelerated path needs a GPU (there is no CPU fallback); '
                                   f'--device={config.device} cannot be honoured')
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    if world > 1:
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
-        dist.init_process_group(os.environ.get('TRACEVAE_DIST_BACKEND', 'nccl'))
+    rank, world = init_distributed()
     if config.device in (None, 'cpu') and rank == 0:
         print(f'note: --device={config.device} ignored, running on cuda:{torch.cuda.current_device()}')
     sets, id_manager, latency_range = load_dataset(config.dataset.root_dir)
@@ -511,7 +700,8 @@ def main(argv=None) -> int:
     stores = {'train': DeviceTraceStore(sets['train'], latency_range, v),
               'val': DeviceTraceStore(sets['val'], latency_range, v),
               'test': DeviceTraceStore(concat_flat(sets[n] for n in TEST_SETS), latency_range, v)}
-    result = fit(config, stores, v, out_dir, rank=rank, world_size=world)
+    result = run_with_nan_restart(
+        lambda: fit(config, stores, v, out_dir, rank=rank, world_size=world), out_dir, rank, world)
     if rank == 0:
         print(json.dumps({k: val for k, val in result.items() if not k.startswith('_')}, indent=1))
     if world > 1:
