@@ -342,10 +342,17 @@ int tv_latdec_rows_bwd(int64_t n_samples, int64_t rows_per_rep, int64_t batch, i
  * (tensor_utils.py:54-67, model/struct_vae.py:281-294), never materialising [K,B,M,M]:
  * ll[k,b] = sum_{i<j} f(adj*l - softplus(l)), l = <h[k,b,i,:], h[k,b,j,:]>,
  * f(x) = x < log(threshold) ? alpha*x : x when biased (distributions.py:125-134).
+ * The contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32), one wave per 32x32 tile of node
+ * pairs, the grid spans (sample, trace) x tiles.  max_node_count <= 1536, dim <= 80.
+ * fwd workspace (tv_adj_bernoulli_ll_fwd_workspace_bytes): one partial sum per workgroup, added
+ * per trace in a fixed order by a second kernel.
  * bwd: dh given d(ll). */
+int64_t tv_adj_bernoulli_ll_fwd_workspace_bytes(int64_t n_samples, int64_t batch,
+                                                int64_t max_node_count);
 int tv_adj_bernoulli_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                             int64_t dim, const float *h, const float *adj, int biased,
-                            float alpha, float log_threshold, float *ll, void *stream);
+                            float alpha, float log_threshold, float *ll, void *workspace,
+                            int64_t workspace_bytes, void *stream);
 int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                             int64_t dim, const float *h, const float *adj, int biased,
                             float alpha, float log_threshold, const float *dll, float *dh,

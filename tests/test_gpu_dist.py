@@ -68,7 +68,7 @@ def test_two_rank_step_equals_averaged_gradients(device, tmp_path):
         tr = _trainer(device, 1)
         G, eps = _shard(rank)
         seen = {}
-        tr.all_reduce_gradients = lambda tr=tr, seen=seen: seen.update(g=tr.flat.grad.clone())
+        tr.exchange = lambda loss=None, tr=tr, seen=seen: seen.update(g=tr.flat.grad.clone())
         tr.optimizer.step = lambda *a, **k: None
         losses.append(tr.step(G, eps=eps)['loss'].cpu())
         grads.append(seen['g'])
@@ -77,7 +77,7 @@ def test_two_rank_step_equals_averaged_gradients(device, tmp_path):
     for rank in range(world):
         tr = _trainer(device, 1)
         G, eps = _shard(rank)
-        tr.all_reduce_gradients = lambda tr=tr: tr.flat.grad.copy_(mean)
+        tr.exchange = lambda loss=None, tr=tr: tr.flat.grad.copy_(mean)
         tr.step(G, eps=eps)
         want = tr.flat.flat.detach().cpu()
         assert torch.allclose(got[rank]['flat'], want, rtol=1e-6, atol=1e-7)

@@ -9,154 +9,220 @@ namespace {
 constexpr float LOG_2PI = 1.8378770664093453f;
 
 // ------------------------------------------------------------------------------------
-// p(adj | z): l_ij = <h_i, h_j> for i < j, Bernoulli log-likelihood over all T pairs.
-// One workgroup per (sample, trace).  64x64 pair tiles, 4x4 pairs per thread; the two
-// 64-row slices of h sit in LDS as [d][row] (row stride 68) so the operand reads are
-// float4 and conflict-free.  [K,B,M,M] is never materialised.
+// p(adj | z) on the matrix cores: l_ij = <h_i, h_j> for i < j, Bernoulli log-likelihood over
+// all T = M(M-1)/2 pairs (tensor_utils.py:54-67, struct_vae.py:281-294).  [K,B,M,M] is never
+// materialised: a wave owns one 32x32 tile of node pairs, forms its logits with a chain of
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) and applies softplus / the biased rule to the 16
+// logits each lane then holds.
+//
+// Operand layout.  A 32x32x2 step multiplies A[i = lane&31][k = lane>>5] by
+// B[k = lane>>5][j = lane&31].  The contraction index is split in two halves of Dh = ceil(D/2):
+// lanes 0-31 walk k = 0 .. Dh-1, lanes 32-63 walk k = Dh .. D-1, so a lane reads one contiguous
+// half of its h row (float4 loads when D % 8 == 0) and step s pairs k = s with k = Dh + s, the
+// same for both operands: a fixed summation order.  Steps beyond Dh multiply zeros.
+// C/D layout: lane holds column lane&31, rows (r&3) + 8(r>>2) + 4(lane>>5) in register r.
+//
+// Grid: forward  = (sample, trace) x groups of four tiles of the upper block triangle; each
+//                  workgroup writes ONE partial sum, a second kernel adds a trace's partials
+//                  in order (float64) - fixed order, no atomics;
+//       backward = (sample, trace) x 32-row block I; the four waves of a workgroup split the
+//                  column blocks J, each forms X = G_JI (j in registers, i on the lane), which
+//                  is at once the A operand of dH_I += X^T H_J (the sum runs over X's row
+//                  index, so no lane movement), and the four partial dH_I tiles are added in
+//                  wave order through LDS.
+// adj is read in its coalesced orientation (lane = the larger node index) into a 32x33 LDS
+// tile per wave and picked up from there in whatever orientation the tile needs.
 // Algorithmic bytes per (k,b): 4*M*D (h) + 4*T (adj, L2-resident across the K samples).
 // ------------------------------------------------------------------------------------
-constexpr int PT = 64;         // pair-tile edge
-constexpr int HS = 68;         // LDS row stride of the h slices
+constexpr int AT = 32;                 // pair-tile edge
+constexpr int ATS = AT + 1;            // LDS row stride of the adj tile
+constexpr int ADJ_WAVES = 4;           // waves per workgroup
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void load_h_slice(float *dst, const float *h, int64_t row0, int64_t M,
-                                             int D) {
-  // dst[d][r] = h[row0 + r][d], zero beyond M
-  for (int e = threadIdx.x; e < PT * D; e += blockDim.x) {
-    const int r = e / D, d = e - r * D;
-    dst[d * HS + r] = (row0 + r < M) ? h[(row0 + r) * D + d] : 0.f;
-  }
-}
-
-__device__ __forceinline__ void pair_logits(float (&l)[4][4], const float *hi, const float *hj,
-                                            int D, int ty, int tx) {
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) l[a][b] = 0.f;
-  for (int d = 0; d < D; ++d) {
-    const float4 x = *reinterpret_cast<const float4 *>(&hi[d * HS + ty * 4]);
-    const float4 y = *reinterpret_cast<const float4 *>(&hj[d * HS + tx * 4]);
-    const float xa[4] = {x.x, x.y, x.z, x.w}, yb[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) l[a][b] = fmaf(xa[a], yb[b], l[a][b]);
-  }
-}
-
-__device__ __forceinline__ int64_t triu_index(int64_t i, int64_t j, int64_t M) {
+__device__ __forceinline__ int triu_index32(int i, int j, int M) {   // i < j < M <= 1536
   return i * (2 * M - i - 1) / 2 + (j - i - 1);
 }
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-__global__ __launch_bounds__(256) void adj_ll_fwd_kernel(int64_t B, int64_t M, int D,
-                                                         const float *__restrict__ h,
-                                                         const float *__restrict__ adj,
-                                                         int biased, float alpha, float log_thr,
-                                                         float *__restrict__ ll) {
-  extern __shared__ __align__(16) float lds[];
-  float *hi = lds, *hj = lds + D * HS;
-  __shared__ float red[256];
-  const int64_t kb = blockIdx.x, b = kb % B;
+// this lane's half of row `row` of h: a[s] = h[row][half*Dh + s], zero beyond the half / D
+template <int NV, bool VEC>
+__device__ __forceinline__ void load_h_half(float (&a)[4 * NV], const float *__restrict__ hb,
+                                            int row, int D, int Dh, int half) {
+  const float *p = hb + (int64_t)row * D + half * Dh;
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (4 * q < Dh) v = *reinterpret_cast<const float4 *>(p + 4 * q);
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+  } else {
+    const int valid = min(Dh, D - half * Dh);
+#pragma unroll
+    for (int s = 0; s < 4 * NV; ++s) a[s] = (s < valid) ? p[s] : 0.f;
+  }
+}
+
+// the 32x32 adj tile of (row block rb <= column block cb) into S[r][c]: entries with global
+// row < column < M, zero elsewhere; lanes run along the column (coalesced 128-byte rows)
+__device__ __forceinline__ void stage_adj_tile(float *S, const float *__restrict__ ab, int rb,
+                                               int cb, int M, int lane) {
+  const int c = lane & 31, half = lane >> 5, gc = cb * AT + c;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int r = 2 * t + half, gr = rb * AT + r;
+    S[r * ATS + c] = (gr < gc && gc < M) ? ab[triu_index32(gr, gc, M)] : 0.f;
+  }
+}
+
+template <int NV, bool VEC>
+__global__ __launch_bounds__(64 * ADJ_WAVES) void adj_ll_fwd_kernel(
+    int64_t B, int M, int D, int nb, int ntiles, int ngroups, const float *__restrict__ h,
+    const float *__restrict__ adj, int biased, float alpha, float log_thr,
+    float *__restrict__ partial) {
+  __shared__ float red[ADJ_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+  const int64_t kb = blockIdx.x / ngroups;
+  const int group = (int)(blockIdx.x - kb * ngroups);
   const float *hb = h + kb * M * D;
-  const float *ab = adj + b * (M * (M - 1) / 2);
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  const int nt = (int)((M + PT - 1) / PT);
+  const float *ab = adj + (kb % B) * ((int64_t)M * (M - 1) / 2);
+  const int Dh = (D + 1) >> 1;
   float acc = 0.f;
-  for (int ti = 0; ti < nt; ++ti) {
-    __syncthreads();
-    load_h_slice(hi, hb, (int64_t)ti * PT, M, D);
-    for (int tj = ti; tj < nt; ++tj) {
-      __syncthreads();
-      load_h_slice(hj, hb, (int64_t)tj * PT, M, D);
-      __syncthreads();
-      float l[4][4];
-      pair_logits(l, hi, hj, D, ty, tx);
+  int t = group * ADJ_WAVES + wave;
+  if (t < ntiles) {
+    int rb = 0;                                   // tile t of the upper block triangle, row-major
+    while (t >= nb - rb) { t -= nb - rb; ++rb; }
+    const int cb = rb + t;
+    float a[4 * NV], b[4 * NV];
+    load_h_half<NV, VEC>(a, hb, min(rb * AT + col, M - 1), D, Dh, half);
+    load_h_half<NV, VEC>(b, hb, min(cb * AT + col, M - 1), D, Dh, half);
+    f32x16 l = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+    for (int s = 0; s < 4 * NV; ++s) l = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], l, 0, 0, 0);
+    const int gj = cb * AT + col;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int64_t gi = (int64_t)ti * PT + ty * 4 + a, gj = (int64_t)tj * PT + tx * 4 + c;
-          if (gi < gj && gj < M) {
-            const float x = ab[triu_index(gi, gj, M)];
-            float lp = x * l[a][c] - tv_softplus(l[a][c]);
-            if (biased && lp < log_thr) lp *= alpha;
-            acc += lp;
-          }
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int gi = rb * AT + acc_row(r, half);
+      if (gi < gj && gj < M) {
+        const float x = ab[triu_index32(gi, gj, M)];
+        float lp = x * l[r] - tv_softplus(l[r]);
+        if (biased && lp < log_thr) lp *= alpha;
+        acc += lp;
+      }
     }
   }
-  red[threadIdx.x] = acc;
+  acc = tv_wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = red[0];
+#pragma unroll
+    for (int w = 1; w < ADJ_WAVES; ++w) s += red[w];
+    partial[blockIdx.x] = s;
   }
-  if (threadIdx.x == 0) ll[kb] = red[0];
+}
+
+__global__ __launch_bounds__(256) void adj_ll_reduce_kernel(int64_t KB, int ngroups,
+                                                            const float *__restrict__ partial,
+                                                            float *__restrict__ ll) {
+  const int64_t kb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (kb >= KB) return;
+  double s = 0.0;
+  for (int g = 0; g < ngroups; ++g) s += (double)partial[kb * ngroups + g];
+  ll[kb] = (float)s;
 }
 
 // dh_i = sum_{j != i} g_ij h_j,  g_ij = dll * f'(lp_ij) * (adj_ij - sigmoid(l_ij))
-template <int DCH>  // DCH >= ceil(D/4)
-__global__ __launch_bounds__(256) void adj_ll_bwd_kernel(int64_t B, int64_t M, int D,
-                                                         const float *__restrict__ h,
-                                                         const float *__restrict__ adj,
-                                                         int biased, float alpha, float log_thr,
-                                                         const float *__restrict__ dll,
-                                                         float *__restrict__ dh) {
+template <int NV, bool VEC, int ND>     // ND = ceil(D / 32) output column blocks
+__global__ __launch_bounds__(64 * ADJ_WAVES) void adj_ll_bwd_kernel(
+    int64_t B, int M, int D, int nb, const float *__restrict__ h, const float *__restrict__ adj,
+    int biased, float alpha, float log_thr, const float *__restrict__ dll,
+    float *__restrict__ dh) {
   extern __shared__ __align__(16) float lds[];
-  float *hi = lds, *hj = lds + D * HS, *gs = lds + 2 * D * HS;  // gs[64][65]
-  const int64_t kb = blockIdx.x, b = kb % B;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+  float *S = lds + wave * (AT * ATS);                          // this wave's adj tile
+  float *sums = lds + ADJ_WAVES * (AT * ATS);                  // [ADJ_WAVES-1][ND*16][64]
+  const int64_t kb = blockIdx.x / nb;
+  const int ib = (int)(blockIdx.x - kb * nb);
   const float *hb = h + kb * M * D;
-  const float *ab = adj + b * (M * (M - 1) / 2);
+  const float *ab = adj + (kb % B) * ((int64_t)M * (M - 1) / 2);
   const float dl = dll[kb];
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  const int ri = threadIdx.x >> 2, part = threadIdx.x & 3;  // phase 2: row, d = part + 4*dd
-  const int nt = (int)((M + PT - 1) / PT);
-  for (int ti = 0; ti < nt; ++ti) {
-    float acc[DCH];
+  const int Dh = (D + 1) >> 1;
+  const int gi = ib * AT + col;                                // this lane's node i
+  float bi[4 * NV];
+  load_h_half<NV, VEC>(bi, hb, min(gi, M - 1), D, Dh, half);
+  f32x16 acc[ND];
 #pragma unroll
-    for (int dd = 0; dd < DCH; ++dd) acc[dd] = 0.f;
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  const int rounds = (nb + ADJ_WAVES - 1) / ADJ_WAVES;         // every wave meets every barrier
+  for (int it = 0; it < rounds; ++it) {
+    const int jb = it * ADJ_WAVES + wave;
+    const bool live = jb < nb;
+    f32x16 x = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      float aj[4 * NV];
+      load_h_half<NV, VEC>(aj, hb, min(jb * AT + col, M - 1), D, Dh, half);
+#pragma unroll
+      for (int s = 0; s < 4 * NV; ++s) x = __builtin_amdgcn_mfma_f32_32x32x2f32(aj[s], bi[s], x, 0, 0, 0);
+      stage_adj_tile(S, ab, min(ib, jb), max(ib, jb), M, lane);
+    }
     __syncthreads();
-    load_h_slice(hi, hb, (int64_t)ti * PT, M, D);
-    for (int tj = 0; tj < nt; ++tj) {
-      __syncthreads();
-      load_h_slice(hj, hb, (int64_t)tj * PT, M, D);
-      __syncthreads();
-      float l[4][4];
-      pair_logits(l, hi, hj, D, ty, tx);
+    if (live) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int64_t gi = (int64_t)ti * PT + ty * 4 + a, gj = (int64_t)tj * PT + tx * 4 + c;
-          float g = 0.f;
-          if (gi != gj && gi < M && gj < M) {
-            const int64_t lo = gi < gj ? gi : gj, hi_ = gi < gj ? gj : gi;
-            const float x = ab[triu_index(lo, hi_, M)];
-            const float lv = l[a][c];
-            const float lp = x * lv - tv_softplus(lv);
-            const float sg = 1.0f / (1.0f + expf(-lv));
-            g = dl * (x - sg);
-            if (biased && lp < log_thr) g *= alpha;
-          }
-          gs[(ty * 4 + a) * 65 + tx * 4 + c] = g;
+      for (int r = 0; r < 16; ++r) {
+        const int jl = acc_row(r, half), gj = jb * AT + jl;
+        // S is [smaller node][larger node] of the block pair
+        int sr, sc;
+        if (jb > ib) { sr = col; sc = jl; }
+        else if (jb < ib) { sr = jl; sc = col; }
+        else { sr = min(col, jl); sc = max(col, jl); }
+        const float av = S[sr * ATS + sc];
+        float g = 0.f;
+        if (gi != gj && gi < M && gj < M) {
+          const float lv = x[r];
+          const float lp = av * lv - tv_softplus(lv);
+          const float sg = 1.0f / (1.0f + expf(-lv));
+          g = dl * (av - sg);
+          if (biased && lp < log_thr) g *= alpha;
         }
-      __syncthreads();
+        x[r] = g;
+      }
+      // dH_I += X^T H_J: A = X as it stands (i on the lane, j = the register's row), B = H_J
 #pragma unroll
-      for (int dd = 0; dd < DCH; ++dd) {
-        const int d = part + 4 * dd;
-        if (d < D) {
-          float s = acc[dd];
-          for (int j = 0; j < PT; ++j) s = fmaf(gs[ri * 65 + j], hj[d * HS + j], s);
-          acc[dd] = s;
+      for (int d = 0; d < ND; ++d) {
+        const int dc = d * AT + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gj = min(jb * AT + acc_row(r, half), M - 1);
+          const float hv = (dc < D) ? hb[(int64_t)gj * D + dc] : 0.f;
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[r], hv, acc[d], 0, 0, 0);
         }
       }
     }
-    const int64_t gi = (int64_t)ti * PT + ri;
-    if (gi < M) {
+    __syncthreads();
+  }
+  // the four partial tiles, added in wave order
+  if (wave > 0) {
+    float *dst = sums + (wave - 1) * (ND * 16 * 64);
 #pragma unroll
-      for (int dd = 0; dd < DCH; ++dd) {
-        const int d = part + 4 * dd;
-        if (d < D) dh[(kb * M + gi) * D + d] = acc[dd];
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64 + lane] = acc[d][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const int dc = d * AT + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[d][r];
+#pragma unroll
+        for (int w = 1; w < ADJ_WAVES; ++w) v += sums[(w - 1) * (ND * 16 * 64) + (d * 16 + r) * 64 + lane];
+        const int row = ib * AT + acc_row(r, half);
+        if (row < M && dc < D) dh[(kb * M + row) * D + dc] = v;
       }
     }
   }
@@ -412,40 +478,98 @@ __global__ __launch_bounds__(256) void score_reduce_kernel(int64_t K, int64_t B,
 
 }  // namespace
 
+// tiles and workgroups of the forward pass
+static inline void adj_geometry(int64_t M, int *nb, int *ntiles, int *ngroups) {
+  *nb = (int)tv_cdiv(M, AT);
+  *ntiles = *nb * (*nb + 1) / 2;
+  *ngroups = (*ntiles + ADJ_WAVES - 1) / ADJ_WAVES;
+}
+
+extern "C" int64_t tv_adj_bernoulli_ll_fwd_workspace_bytes(int64_t n_samples, int64_t batch,
+                                                           int64_t max_node_count) {
+  if (n_samples < 1 || batch < 0 || max_node_count < 2) return 0;
+  int nb, ntiles, ngroups;
+  adj_geometry(max_node_count, &nb, &ntiles, &ngroups);
+  return (int64_t)sizeof(float) * n_samples * batch * ngroups;
+}
+
+static int adj_check(const char *who, int64_t n_samples, int64_t batch, int64_t max_node_count,
+                     int64_t dim) {
+  TV_REQUIRE(n_samples >= 1 && batch >= 0 && max_node_count >= 2, "%s: bad sizes", who);
+  TV_REQUIRE(max_node_count <= 1536, "%s: max_node_count must be <= 1536: got %lld", who,
+             (long long)max_node_count);
+  TV_REQUIRE(dim >= 1 && dim <= 80, "%s: dim must be in [1,80]: got %lld", who, (long long)dim);
+  int nb, ntiles, ngroups;
+  adj_geometry(max_node_count, &nb, &ntiles, &ngroups);
+  TV_REQUIRE(n_samples * batch * (int64_t)(ngroups > nb ? ngroups : nb) < (int64_t)1 << 31,
+             "%s: n_samples * batch too large for one launch", who);
+  return TV_OK;
+}
+
+// the two launches of the forward pass; `partial` holds n_samples * batch * ngroups floats
+static int adj_fwd_launch(int64_t n_samples, int64_t batch, int64_t M, int64_t dim, const float *h,
+                          const float *adj, int biased, float alpha, float log_threshold,
+                          float *partial, float *ll, hipStream_t s) {
+  int nb, ntiles, ngroups;
+  adj_geometry(M, &nb, &ntiles, &ngroups);
+  const int64_t KB = n_samples * batch;
+  const dim3 grid((unsigned)(KB * ngroups)), block(64 * ADJ_WAVES);
+  const bool vec = dim % 8 == 0;
+#define ADJ_FWD(NV, VEC)                                                                        \
+  hipLaunchKernelGGL((adj_ll_fwd_kernel<NV, VEC>), grid, block, 0, s, batch, (int)M, (int)dim,  \
+                     nb, ntiles, ngroups, h, adj, biased, alpha, log_threshold, partial)
+  if (dim <= 40) { if (vec) ADJ_FWD(5, true); else ADJ_FWD(5, false); }
+  else { if (vec) ADJ_FWD(10, true); else ADJ_FWD(10, false); }
+#undef ADJ_FWD
+  TV_LAUNCH_CHECK("tv_adj_bernoulli_ll_fwd");
+  hipLaunchKernelGGL(adj_ll_reduce_kernel, dim3((unsigned)tv_cdiv(KB, 256)), dim3(256), 0, s, KB,
+                     ngroups, partial, ll);
+  TV_LAUNCH_CHECK("tv_adj_bernoulli_ll_fwd (reduce)");
+  return TV_OK;
+}
+
 extern "C" int tv_adj_bernoulli_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                                        int64_t dim, const float *h, const float *adj, int biased,
-                                       float alpha, float log_threshold, float *ll, void *stream) {
-  TV_REQUIRE(n_samples >= 1 && batch >= 0 && max_node_count >= 2, "tv_adj_bernoulli_ll_fwd: bad sizes");
-  TV_REQUIRE(dim >= 1 && dim <= 80, "tv_adj_bernoulli_ll_fwd: dim must be in [1,80]: got %lld",
-             (long long)dim);
+                                       float alpha, float log_threshold, float *ll,
+                                       void *workspace, int64_t workspace_bytes, void *stream) {
+  const int rc = adj_check("tv_adj_bernoulli_ll_fwd", n_samples, batch, max_node_count, dim);
+  if (rc != TV_OK) return rc;
   if (batch == 0) return TV_OK;
   TV_REQUIRE(h && adj && ll, "tv_adj_bernoulli_ll_fwd: null pointer");
-  const size_t ldsb = sizeof(float) * 2 * dim * HS;
-  hipLaunchKernelGGL(adj_ll_fwd_kernel, dim3((unsigned)(n_samples * batch)), dim3(256), ldsb,
-                     (hipStream_t)stream, batch, max_node_count, (int)dim, h, adj, biased, alpha,
-                     log_threshold, ll);
-  TV_LAUNCH_CHECK("tv_adj_bernoulli_ll_fwd");
-  return TV_OK;
+  const int64_t need = tv_adj_bernoulli_ll_fwd_workspace_bytes(n_samples, batch, max_node_count);
+  if (!workspace || workspace_bytes < need) {
+    tv_set_error("tv_adj_bernoulli_ll_fwd: workspace of %lld bytes needed, got %lld",
+                 (long long)need, (long long)workspace_bytes);
+    return TV_ERR_WORKSPACE;
+  }
+  return adj_fwd_launch(n_samples, batch, max_node_count, dim, h, adj, biased, alpha,
+                        log_threshold, (float *)workspace, ll, (hipStream_t)stream);
 }
 
 extern "C" int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                                        int64_t dim, const float *h, const float *adj, int biased,
                                        float alpha, float log_threshold, const float *dll,
                                        float *dh, void *stream) {
-  TV_REQUIRE(n_samples >= 1 && batch >= 0 && max_node_count >= 2, "tv_adj_bernoulli_ll_bwd: bad sizes");
-  TV_REQUIRE(dim >= 1 && dim <= 80, "tv_adj_bernoulli_ll_bwd: dim must be in [1,80]: got %lld",
-             (long long)dim);
+  const int rc = adj_check("tv_adj_bernoulli_ll_bwd", n_samples, batch, max_node_count, dim);
+  if (rc != TV_OK) return rc;
   if (batch == 0) return TV_OK;
   TV_REQUIRE(h && adj && dll && dh, "tv_adj_bernoulli_ll_bwd: null pointer");
-  const size_t ldsb = sizeof(float) * (2 * dim * HS + 64 * 65);
-  const dim3 grid((unsigned)(n_samples * batch)), block(256);
+  int nb, ntiles, ngroups;
+  adj_geometry(max_node_count, &nb, &ntiles, &ngroups);
+  const int M = (int)max_node_count, D = (int)dim;
+  const int nd = (D + AT - 1) / AT;
+  const size_t ldsb = sizeof(float) * (ADJ_WAVES * AT * ATS + (ADJ_WAVES - 1) * nd * 16 * 64);
+  const dim3 grid((unsigned)(n_samples * batch * nb)), block(64 * ADJ_WAVES);
   hipStream_t s = (hipStream_t)stream;
-  if (dim <= 40)
-    hipLaunchKernelGGL((adj_ll_bwd_kernel<10>), grid, block, ldsb, s, batch, max_node_count,
-                       (int)dim, h, adj, biased, alpha, log_threshold, dll, dh);
-  else
-    hipLaunchKernelGGL((adj_ll_bwd_kernel<20>), grid, block, ldsb, s, batch, max_node_count,
-                       (int)dim, h, adj, biased, alpha, log_threshold, dll, dh);
+  const bool vec = dim % 8 == 0;
+#define ADJ_BWD(NV, VEC, ND)                                                                   \
+  hipLaunchKernelGGL((adj_ll_bwd_kernel<NV, VEC, ND>), grid, block, ldsb, s, batch, M, D, nb,  \
+                     h, adj, biased, alpha, log_threshold, dll, dh)
+  if (nd == 1) { if (vec) ADJ_BWD(5, true, 1); else ADJ_BWD(5, false, 1); }
+  else if (dim <= 40) { if (vec) ADJ_BWD(5, true, 2); else ADJ_BWD(5, false, 2); }
+  else if (nd == 2) { if (vec) ADJ_BWD(10, true, 2); else ADJ_BWD(10, false, 2); }
+  else { if (vec) ADJ_BWD(10, true, 3); else ADJ_BWD(10, false, 3); }
+#undef ADJ_BWD
   TV_LAUNCH_CHECK("tv_adj_bernoulli_ll_bwd");
   return TV_OK;
 }

@@ -718,8 +718,10 @@ class _AdjLL(Function):
         batch = adj.shape[0]
         m, dim = h.shape[-2], h.shape[-1]
         ll = torch.empty([n_samples * batch], dtype=_f32, device=h.device)
+        wsb = hip.query('tv_adj_bernoulli_ll_fwd_workspace_bytes', n_samples, batch, m)
+        ws = _workspace(wsb, h.device)
         hip.call('tv_adj_bernoulli_ll_fwd', n_samples, batch, m, dim, hip.ptr(h), hip.ptr(adj),
-                 int(biased), float(alpha), float(log_thr), hip.ptr(ll))
+                 int(biased), float(alpha), float(log_thr), hip.ptr(ll), hip.ptr(ws), wsb)
         ctx.save_for_backward(h, adj)
         ctx.args = (n_samples, batch, m, dim, int(biased), float(alpha), float(log_thr))
         return ll
