@@ -358,6 +358,19 @@ int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_c
                             float alpha, float log_threshold, const float *dll, float *dh,
                             void *stream);
 
+/* No counterpart in the reference: tv_adj_bernoulli_ll_fwd for callers that cannot allocate
+ * device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  Same inputs, outputs and results, no workspace argument: the partial sums live
+ * in a device array the library holds on every GPU it runs on (TV_ADJ_STATIC_MAX_PARTIALS
+ * floats = 4 MiB, until the process ends).  Calls whose n_samples * batch * tile groups
+ * (= tv_adj_bernoulli_ll_fwd_workspace_bytes / 4) exceed that return TV_ERR_WORKSPACE.  The
+ * call makes no hipMalloc / hipFree.  All calls on one GPU share the array: calls that overlap
+ * on one GPU (different streams) race - serialise them. */
+#define TV_ADJ_STATIC_MAX_PARTIALS (1 << 20)
+int tv_adj_bernoulli_ll_fwd_static(int64_t n_samples, int64_t batch, int64_t max_node_count,
+                                   int64_t dim, const float *h, const float *adj, int biased,
+                                   float alpha, float log_threshold, float *ll, void *stream);
+
 /* Categorical log-prob per row: ll[r] = log_softmax(logits[r,:])[target[r % target_rows]]
  * (tk.Categorical, model/struct_vae.py:258-266 and :413); optional biased variant.
  * fwd also returns the row log-sum-exp for the backward pass.

@@ -44,6 +44,7 @@ def test_host_side_validation_without_gpu():
     assert lib.tv_gat_scores(10, 2, 6, one, one, one, one, one, None) == -1
     assert lib.tv_adj_bernoulli_ll_fwd(1, 2, 8, 500, one, one, 0, 1.0, 0.0, one, one, 64, None) == -1
     assert lib.tv_adj_bernoulli_ll_fwd(1, 2, 8, 40, one, one, 0, 1.0, 0.0, one, one, 4, None) == -3   # workspace too small
+    assert lib.tv_adj_bernoulli_ll_fwd_static(1, 2, 2000, 40, one, one, 0, 1.0, 0.0, one, None) == -1
     assert lib.tv_rowdot_fwd(5, 10, 9, one, one, None, one, None) == -1
     assert lib.tv_optim_step(3, 10, one, one, one, None, None, 0.0, 1e-3, 0.0, 0.99, 1e-8, 1, None) == -1
 

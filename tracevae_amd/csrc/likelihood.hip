@@ -4,6 +4,8 @@
 // All sums are fixed-order (per-thread partials -> wave / workgroup tree), no atomics.
 #include "tv_common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr float LOG_2PI = 1.8378770664093453f;
@@ -544,6 +546,61 @@ extern "C" int tv_adj_bernoulli_ll_fwd(int64_t n_samples, int64_t batch, int64_t
   }
   return adj_fwd_launch(n_samples, batch, max_node_count, dim, h, adj, biased, alpha,
                         log_threshold, (float *)workspace, ll, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------
+// tv_adj_bernoulli_ll_fwd_static: the same forward pass for callers that cannot allocate (HIP
+// graph capture, tight serving loops).  The per-workgroup partial sums go to a file-scope
+// device array instead of a caller workspace.  The array's NAME is a host-side stand-in, not a
+// device address: every GPU holds its own copy at its own address, looked up once per device
+// with hipGetSymbolAddress and kept; kernels only ever see that looked-up pointer.
+// Every call on a GPU shares that GPU's array: the forward kernel overwrites every partial the
+// reduce kernel of the same call reads (nothing has to start at zero), and calls that overlap
+// on one GPU (two streams) race.
+// ------------------------------------------------------------------------------------
+static __device__ __align__(256) float scratch[TV_ADJ_STATIC_MAX_PARTIALS];
+
+constexpr int ADJ_MAX_DEVICES = 64;
+static std::mutex adj_scratch_mutex;
+static float *adj_scratch_ptr[ADJ_MAX_DEVICES];     // per device, filled on first use
+
+static int adj_static_scratch(float **out) {
+  int dev = -1;
+  TV_HIP(hipGetDevice(&dev));
+  TV_REQUIRE(dev >= 0 && dev < ADJ_MAX_DEVICES, "tv_adj_bernoulli_ll_fwd_static: device %d", dev);
+  std::lock_guard<std::mutex> guard(adj_scratch_mutex);
+  if (adj_scratch_ptr[dev] == nullptr) {
+    void *p = nullptr;
+    TV_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));      // with device `dev` current
+    TV_REQUIRE(p != nullptr, "tv_adj_bernoulli_ll_fwd_static: no address for the scratch array");
+    adj_scratch_ptr[dev] = (float *)p;
+  }
+  *out = adj_scratch_ptr[dev];
+  return TV_OK;
+}
+
+extern "C" int tv_adj_bernoulli_ll_fwd_static(int64_t n_samples, int64_t batch,
+                                              int64_t max_node_count, int64_t dim,
+                                              const float *h, const float *adj, int biased,
+                                              float alpha, float log_threshold, float *ll,
+                                              void *stream) {
+  int rc = adj_check("tv_adj_bernoulli_ll_fwd_static", n_samples, batch, max_node_count, dim);
+  if (rc != TV_OK) return rc;
+  if (batch == 0) return TV_OK;
+  TV_REQUIRE(h && adj && ll, "tv_adj_bernoulli_ll_fwd_static: null pointer");
+  const int64_t need =
+      tv_adj_bernoulli_ll_fwd_workspace_bytes(n_samples, batch, max_node_count) / (int64_t)sizeof(float);
+  if (need > TV_ADJ_STATIC_MAX_PARTIALS) {
+    tv_set_error("tv_adj_bernoulli_ll_fwd_static: n_samples * batch * tile groups = %lld partial "
+                 "sums exceed the static scratch of %d: use tv_adj_bernoulli_ll_fwd with a "
+                 "workspace", (long long)need, TV_ADJ_STATIC_MAX_PARTIALS);
+    return TV_ERR_WORKSPACE;
+  }
+  float *partial = nullptr;
+  rc = adj_static_scratch(&partial);
+  if (rc != TV_OK) return rc;
+  return adj_fwd_launch(n_samples, batch, max_node_count, dim, h, adj, biased, alpha,
+                        log_threshold, partial, ll, (hipStream_t)stream);
 }
 
 extern "C" int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
