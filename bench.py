@@ -77,10 +77,16 @@ def make_config(width=None, z_dim=10):
     parse_flags(cfg, [f'--model.struct.z_dim={z_dim}', '--model.struct.decoder.use_prior_flow=true',
                       '--train.z_unit_ball_reg=1', f'--model.latency.z2_dim={z_dim}',
                       '--model.latency.decoder.condition_on_z=true'])
-    if width is not None:     # configs[4]: doubled GNN width
+    if width is not None:     # configs[4]: doubled latent / GNN / MLP widths
         mc = cfg.model
         for sec in (mc.struct.encoder, mc.struct.decoder, mc.latency.encoder, mc.latency.decoder):
             sec.gnn_layers = [width] * len(sec.gnn_layers)
+        if width >= 1000:
+            sd, ld = mc.struct.decoder, mc.latency.decoder
+            sd.latent_embedding_size *= 2
+            sd.node_count_layers = [2 * w for w in sd.node_count_layers]
+            sd.graph_embedding_layers = [2 * w for w in sd.graph_embedding_layers]
+            ld.z2_given_z_hidden_layers = [2 * w for w in ld.z2_given_z_hidden_layers]
     return cfg
 
 

@@ -346,17 +346,21 @@ int tv_latdec_rows_bwd(int64_t n_samples, int64_t rows_per_rep, int64_t batch, i
  * pairs, the grid spans (sample, trace) x tiles.  max_node_count <= 1536, dim <= 80.
  * fwd workspace (tv_adj_bernoulli_ll_fwd_workspace_bytes): one partial sum per workgroup, added
  * per trace in a fixed order by a second kernel.
- * bwd: dh given d(ll). */
+ * bwd: dh given d(ll); workspace (0 bytes for most shapes): with few traces of many nodes the
+ * column blocks of a row block are split over several workgroups, whose partial dh tiles are
+ * added in a fixed order. */
 int64_t tv_adj_bernoulli_ll_fwd_workspace_bytes(int64_t n_samples, int64_t batch,
                                                 int64_t max_node_count);
 int tv_adj_bernoulli_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                             int64_t dim, const float *h, const float *adj, int biased,
                             float alpha, float log_threshold, float *ll, void *workspace,
                             int64_t workspace_bytes, void *stream);
+int64_t tv_adj_bernoulli_ll_bwd_workspace_bytes(int64_t n_samples, int64_t batch,
+                                                int64_t max_node_count, int64_t dim);
 int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                             int64_t dim, const float *h, const float *adj, int biased,
                             float alpha, float log_threshold, const float *dll, float *dh,
-                            void *stream);
+                            void *workspace, int64_t workspace_bytes, void *stream);
 
 /* No counterpart in the reference: tv_adj_bernoulli_ll_fwd for callers that cannot allocate
  * device memory (code under HIP graph capture, tight serving loops, harnesses that forbid

@@ -160,8 +160,35 @@ def bench_misc():
     print(f'embedding bwd N={db.num_nodes} V=1001: {ms:.3f} ms', flush=True)
 
 
+def bench_adj():
+    """tv_adj_bernoulli_ll_* through the C-ABI: configs[1] training (512 traces, M = 100),
+    configs[3] scoring (K = 100 x 128), configs[4] (8 and 32 traces of M = 500)."""
+    import math
+    for name, K, B, M, D, biased in (('train C2', 1, 512, 100, 40, 0), ('score K=100', 100, 128, 100, 40, 1),
+                                     ('C5 B=8 D=40', 1, 8, 500, 40, 0), ('C5 B=8 D=80', 1, 8, 500, 80, 0),
+                                     ('C5 B=32 D=80', 1, 32, 500, 80, 0), ('C5 score K=10', 10, 8, 500, 80, 1)):
+        h = torch.randn(K * B, M, D, device=DEV) * 0.3
+        adj = (torch.rand(B, M * (M - 1) // 2, device=DEV) < 0.02).float()
+        ll = torch.empty(K * B, device=DEV)
+        dll = torch.randn(K * B, device=DEV)
+        dh = torch.empty_like(h)
+        wsb = hip.query('tv_adj_bernoulli_ll_fwd_workspace_bytes', K, B, M)
+        ws = torch.empty(max(wsb // 4, 1), device=DEV)
+        wsb2 = hip.query('tv_adj_bernoulli_ll_bwd_workspace_bytes', K, B, M, D)
+        ws2 = torch.empty(max(wsb2 // 4, 1), device=DEV)
+        args = (K, B, M, D, hip.ptr(h), hip.ptr(adj), biased, float(M), math.log(0.5))
+        f = timeit(lambda: hip.call('tv_adj_bernoulli_ll_fwd', *args, hip.ptr(ll), hip.ptr(ws), wsb), reps=50)
+        b = timeit(lambda: hip.call('tv_adj_bernoulli_ll_bwd', *args, hip.ptr(dll), hip.ptr(dh),
+                                    hip.ptr(ws2), wsb2), reps=50)
+        pairs = K * B * M * (M - 1) / 2
+        print(f'adj_ll {name:14s} K*B={K * B:6d} M={M} D={D}: fwd {1e3 * f:8.1f} us '
+              f'({2 * D * pairs / f / 1e9:6.2f} TF), bwd {1e3 * b:8.1f} us '
+              f'({6 * D * pairs / b / 1e9:6.2f} TF)', flush=True)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['gemm', 'gat', 'norm', 'misc']
     torch.cuda.set_device(0)
     for w in what:
-        {'gemm': bench_gemm, 'gat': bench_gat, 'norm': bench_norm, 'misc': bench_misc}[w]()
+        {'gemm': bench_gemm, 'gat': bench_gat, 'norm': bench_norm, 'misc': bench_misc,
+         'adj': bench_adj}[w]()

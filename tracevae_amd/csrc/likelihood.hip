@@ -46,6 +46,18 @@ __device__ __forceinline__ int triu_index32(int i, int j, int M) {   // i < j < 
 }
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Bernoulli terms of one logit with ONE exponential: e = exp(-|l|),
+// softplus(l) = max(l, 0) + log(1 + e), sigmoid(l) = l >= 0 ? 1/(1+e) : e/(1+e).
+// v_exp_f32 / v_log_f32 / v_rcp_f32 forms: 1 + e lies in (1, 2], where the hardware log is good
+// to ~1e-7 absolute - the terms are summed next to |l|-sized values.
+__device__ __forceinline__ float adj_log_prob(float x, float l, float e) {
+  return x * l - (fmaxf(l, 0.f) + __logf(1.0f + e));
+}
+__device__ __forceinline__ float adj_sigmoid(float l, float e) {
+  const float r = __frcp_rn(1.0f + e);
+  return l >= 0.f ? r : e * r;
+}
+
 // this lane's half of row `row` of h: a[s] = h[row][half*Dh + s], zero beyond the half / D
 template <int NV, bool VEC>
 __device__ __forceinline__ void load_h_half(float (&a)[4 * NV], const float *__restrict__ hb,
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(64 * ADJ_WAVES) void adj_ll_fwd_kernel(
       const int gi = rb * AT + acc_row(r, half);
       if (gi < gj && gj < M) {
         const float x = ab[triu_index32(gi, gj, M)];
-        float lp = x * l[r] - tv_softplus(l[r]);
+        float lp = adj_log_prob(x, l[r], __expf(-fabsf(l[r])));
         if (biased && lp < log_thr) lp *= alpha;
         acc += lp;
       }
@@ -135,17 +147,21 @@ __global__ __launch_bounds__(256) void adj_ll_reduce_kernel(int64_t KB, int ngro
 }
 
 // dh_i = sum_{j != i} g_ij h_j,  g_ij = dll * f'(lp_ij) * (adj_ij - sigmoid(l_ij))
+// `jsplit` > 1 (few traces of many nodes): the column blocks of one row block are dealt to
+// jsplit workgroups, each writes its partial dH_I tile to `out` = the workspace laid out
+// [K*B][jsplit][M][D], and adj_dh_reduce_kernel adds the jsplit partials in order.
 template <int NV, bool VEC, int ND>     // ND = ceil(D / 32) output column blocks
 __global__ __launch_bounds__(64 * ADJ_WAVES) void adj_ll_bwd_kernel(
-    int64_t B, int M, int D, int nb, const float *__restrict__ h, const float *__restrict__ adj,
-    int biased, float alpha, float log_thr, const float *__restrict__ dll,
-    float *__restrict__ dh) {
+    int64_t B, int M, int D, int nb, int jsplit, const float *__restrict__ h,
+    const float *__restrict__ adj, int biased, float alpha, float log_thr,
+    const float *__restrict__ dll, float *__restrict__ out) {
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
   float *S = lds + wave * (AT * ATS);                          // this wave's adj tile
   float *sums = lds + ADJ_WAVES * (AT * ATS);                  // [ADJ_WAVES-1][ND*16][64]
-  const int64_t kb = blockIdx.x / nb;
-  const int ib = (int)(blockIdx.x - kb * nb);
+  const int js = (int)(blockIdx.x % jsplit);
+  const int64_t tile = blockIdx.x / jsplit, kb = tile / nb;
+  const int ib = (int)(tile - kb * nb);
   const float *hb = h + kb * M * D;
   const float *ab = adj + (kb % B) * ((int64_t)M * (M - 1) / 2);
   const float dl = dll[kb];
@@ -158,9 +174,10 @@ __global__ __launch_bounds__(64 * ADJ_WAVES) void adj_ll_bwd_kernel(
   for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
-  const int rounds = (nb + ADJ_WAVES - 1) / ADJ_WAVES;         // every wave meets every barrier
+  const int stride = ADJ_WAVES * jsplit;
+  const int rounds = (nb + stride - 1) / stride;               // every wave meets every barrier
   for (int it = 0; it < rounds; ++it) {
-    const int jb = it * ADJ_WAVES + wave;
+    const int jb = (it * jsplit + js) * ADJ_WAVES + wave;
     const bool live = jb < nb;
     f32x16 x = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
@@ -184,10 +201,9 @@ __global__ __launch_bounds__(64 * ADJ_WAVES) void adj_ll_bwd_kernel(
         float g = 0.f;
         if (gi != gj && gi < M && gj < M) {
           const float lv = x[r];
-          const float lp = av * lv - tv_softplus(lv);
-          const float sg = 1.0f / (1.0f + expf(-lv));
-          g = dl * (av - sg);
-          if (biased && lp < log_thr) g *= alpha;
+          const float e = __expf(-fabsf(lv));
+          g = dl * (av - adj_sigmoid(lv, e));
+          if (biased && adj_log_prob(av, lv, e) < log_thr) g *= alpha;
         }
         x[r] = g;
       }
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(64 * ADJ_WAVES) void adj_ll_bwd_kernel(
 #pragma unroll
         for (int w = 1; w < ADJ_WAVES; ++w) v += sums[(w - 1) * (ND * 16 * 64) + (d * 16 + r) * 64 + lane];
         const int row = ib * AT + acc_row(r, half);
-        if (row < M && dc < D) dh[(kb * M + row) * D + dc] = v;
+        if (row < M && dc < D) out[((kb * jsplit + js) * M + row) * D + dc] = v;
       }
     }
   }
@@ -480,6 +496,17 @@ __global__ __launch_bounds__(256) void score_reduce_kernel(int64_t K, int64_t B,
 
 }  // namespace
 
+__global__ __launch_bounds__(256) void adj_dh_reduce_kernel(int64_t KB, int64_t MD, int jsplit,
+                                                            const float *__restrict__ part,
+                                                            float *__restrict__ dh) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= KB * MD) return;
+  const int64_t kb = e / MD, r = e - kb * MD;
+  float s = part[(kb * jsplit) * MD + r];
+  for (int j = 1; j < jsplit; ++j) s += part[(kb * jsplit + j) * MD + r];
+  dh[e] = s;
+}
+
 // tiles and workgroups of the forward pass
 static inline void adj_geometry(int64_t M, int *nb, int *ntiles, int *ngroups) {
   *nb = (int)tv_cdiv(M, AT);
@@ -603,10 +630,27 @@ extern "C" int tv_adj_bernoulli_ll_fwd_static(int64_t n_samples, int64_t batch,
                         log_threshold, partial, ll, (hipStream_t)stream);
 }
 
+// how many workgroups share the column blocks of one row block in the backward pass: enough
+// to put ~4 workgroups on every CU when there are few (sample, trace) pairs of many nodes
+static inline int adj_bwd_jsplit(int64_t KB, int nb) {
+  const int most = (nb + ADJ_WAVES - 1) / ADJ_WAVES;          // at least one block per wave
+  int js = 1;
+  while (js < most && KB * nb * js < 1024) ++js;
+  return js;
+}
+
+extern "C" int64_t tv_adj_bernoulli_ll_bwd_workspace_bytes(int64_t n_samples, int64_t batch,
+                                                           int64_t max_node_count, int64_t dim) {
+  if (n_samples < 1 || batch < 1 || max_node_count < 2 || dim < 1) return 0;
+  const int js = adj_bwd_jsplit(n_samples * batch, (int)tv_cdiv(max_node_count, AT));
+  return js > 1 ? (int64_t)sizeof(float) * n_samples * batch * js * max_node_count * dim : 0;
+}
+
 extern "C" int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                                        int64_t dim, const float *h, const float *adj, int biased,
                                        float alpha, float log_threshold, const float *dll,
-                                       float *dh, void *stream) {
+                                       float *dh, void *workspace, int64_t workspace_bytes,
+                                       void *stream) {
   const int rc = adj_check("tv_adj_bernoulli_ll_bwd", n_samples, batch, max_node_count, dim);
   if (rc != TV_OK) return rc;
   if (batch == 0) return TV_OK;
@@ -614,20 +658,36 @@ extern "C" int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t
   int nb, ntiles, ngroups;
   adj_geometry(max_node_count, &nb, &ntiles, &ngroups);
   const int M = (int)max_node_count, D = (int)dim;
+  const int64_t KB = n_samples * batch;
+  const int js = adj_bwd_jsplit(KB, nb);
+  const int64_t need = tv_adj_bernoulli_ll_bwd_workspace_bytes(n_samples, batch, max_node_count, dim);
+  if (need > 0 && (!workspace || workspace_bytes < need)) {
+    tv_set_error("tv_adj_bernoulli_ll_bwd: workspace of %lld bytes needed, got %lld",
+                 (long long)need, (long long)workspace_bytes);
+    return TV_ERR_WORKSPACE;
+  }
+  TV_REQUIRE(KB * nb * js < (int64_t)1 << 31, "tv_adj_bernoulli_ll_bwd: grid too large");
+  float *out = js > 1 ? (float *)workspace : dh;
   const int nd = (D + AT - 1) / AT;
   const size_t ldsb = sizeof(float) * (ADJ_WAVES * AT * ATS + (ADJ_WAVES - 1) * nd * 16 * 64);
-  const dim3 grid((unsigned)(n_samples * batch * nb)), block(64 * ADJ_WAVES);
+  const dim3 grid((unsigned)(KB * nb * js)), block(64 * ADJ_WAVES);
   hipStream_t s = (hipStream_t)stream;
   const bool vec = dim % 8 == 0;
 #define ADJ_BWD(NV, VEC, ND)                                                                   \
   hipLaunchKernelGGL((adj_ll_bwd_kernel<NV, VEC, ND>), grid, block, ldsb, s, batch, M, D, nb,  \
-                     h, adj, biased, alpha, log_threshold, dll, dh)
+                     js, h, adj, biased, alpha, log_threshold, dll, out)
   if (nd == 1) { if (vec) ADJ_BWD(5, true, 1); else ADJ_BWD(5, false, 1); }
   else if (dim <= 40) { if (vec) ADJ_BWD(5, true, 2); else ADJ_BWD(5, false, 2); }
   else if (nd == 2) { if (vec) ADJ_BWD(10, true, 2); else ADJ_BWD(10, false, 2); }
   else { if (vec) ADJ_BWD(10, true, 3); else ADJ_BWD(10, false, 3); }
 #undef ADJ_BWD
   TV_LAUNCH_CHECK("tv_adj_bernoulli_ll_bwd");
+  if (js > 1) {
+    const int64_t MD = (int64_t)M * D;
+    hipLaunchKernelGGL(adj_dh_reduce_kernel, dim3((unsigned)tv_cdiv(KB * MD, 256)), dim3(256), 0,
+                       s, KB, MD, js, out, dh);
+    TV_LAUNCH_CHECK("tv_adj_bernoulli_ll_bwd (reduce)");
+  }
   return TV_OK;
 }
 

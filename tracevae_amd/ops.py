@@ -733,8 +733,10 @@ class _AdjLL(Function):
         k, b, m, dim, biased, alpha, log_thr = ctx.args
         dll = _check(dll, 'dll')
         dh = torch.empty_like(h)
+        wsb = hip.query('tv_adj_bernoulli_ll_bwd_workspace_bytes', k, b, m, dim)
+        ws = _workspace(wsb, h.device)
         hip.call('tv_adj_bernoulli_ll_bwd', k, b, m, dim, hip.ptr(h), hip.ptr(adj), biased, alpha,
-                 log_thr, hip.ptr(dll), hip.ptr(dh))
+                 log_thr, hip.ptr(dll), hip.ptr(dh), hip.ptr(ws), wsb)
         return dh, None, None, None, None, None
 
 
