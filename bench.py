@@ -28,6 +28,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, fp32 matrix (dense)
+GEMM_KERNEL = 'gemm_f32_kernel'
+GEMM_PEAK_TFLOPS = F32_MFMA_PEAK_TFLOPS
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per GEMM launch of the default workload, from the committed --pmc passes
 # (tools/summarize_profile.py traffic; FETCH_SIZE x2 + WRITE_SIZE, separate passes)
@@ -57,12 +59,12 @@ def parse_args():
     ap.add_argument('--max-node-count', type=int, default=100)
     ap.add_argument('--num-operations', type=int, default=1001)
     ap.add_argument('--pool', type=int, default=2048, help='synthetic traces generated per rank')
-    ap.add_argument('--score-k', type=int, default=10, help='n_z of the scoring leg (0 = skip)')
+    ap.add_argument('--score-k', type=int, default=100,
+                    help='n_z of the scoring leg: BASELINE.json configs[3] scores with K = 100 (0 = skip)')
     ap.add_argument('--score-batch', type=int, default=128)
     ap.add_argument('--score-steps', type=int, default=3)
     ap.add_argument('--prior-samples', type=int, default=128,
                     help='traces drawn per call in the prior-sampling leg (N=1 only; 0 = skip)')
-    ap.add_argument('--cpu-baseline-traces', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--gnn-width', type=int, default=None, help='per-head GAT width (default 500)')
     ap.add_argument('--z-dim', type=int, default=10, help='z / z2 dimension (train.sh: 10)')
@@ -90,15 +92,33 @@ def make_config(width=None, z_dim=10):
     return cfg
 
 
-def cpu_baseline(cfg, flat, lr, V, M, n_traces, threads):
-    """The CPU oracle's train step (forward + backward + clip + RMSprop) on `n_traces` traces
-    of the same synthetic set: a bounded sample (about 10-30 s of CPU work)."""
+def _median_rate(fn, units, warmup, timed):
+    """`units` processed per call of `fn`: median units/s over `timed` calls after `warmup`."""
+    for _ in range(warmup):
+        fn()
+    times = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return units / float(np.median(times)), times
+
+
+def cpu_baseline(cfg, flat, lr, V, M, score_k):
+    """The CPU oracle (a port: the reference itself needs dgl / tensorkit / mltk and cannot run
+    here) on bounded samples of the same synthetic set, SURVEY.md section 8d's protocol: warm-up
+    steps, then the median of the timed ones; all host cores, and a one-thread figure.
+      training: batch build + forward + backward + clip + RMSprop on the reference's own batch
+                size of 64 traces (train.py:73);
+      scoring:  batch build + encoders + K decoder passes + log-mean-exp on 4 traces."""
     from oracle.batching import build_batch
     from oracle.model import OracleTraceVAE
     from tracevae_amd.model import TraceVAE
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from helpers import oracle_state, subset_flat
-    torch.set_num_threads(threads)
+    cores = os.cpu_count() or 1
+    # the GPU box reports the whole machine's CPUs; its share is OMP_NUM_THREADS (16)
+    threads = min(cores, int(os.environ.get('OMP_NUM_THREADS', '16') or 16))
     torch.manual_seed(0)
     vae = TraceVAE(cfg.model, V, max_node_count=M)
     for m in vae.modules():
@@ -109,25 +129,45 @@ def cpu_baseline(cfg, flat, lr, V, M, n_traces, threads):
     opt = torch.optim.RMSprop(params, lr=1e-3, alpha=0.99, eps=1e-8)
     orc = OracleTraceVAE(cfg.model, V, M, dtype=torch.float32)
     mean, std = lr.tables(V)
-    sub = subset_flat(flat, np.arange(n_traces))
-    times = []
-    for it in range(2):
-        t0 = time.perf_counter()
+    zd, z2d = cfg.model.struct.z_dim, cfg.model.latency.z2_dim
+
+    def batch_of(n, first=0):
+        sub = subset_flat(flat, np.arange(first, first + n))
         ob = build_batch(sub.node_offsets, sub.u, sub.v, sub.node_type, sub.avg_latency,
                          sub.max_latency, sub.min_latency, mean, std, M)
         ob['node_offsets'] = sub.node_offsets
-        eps_z, eps_z2 = torch.randn(n_traces, 10), torch.randn(n_traces, 10)
+        return ob
+
+    def train_step(n):
+        ob = batch_of(n)
         opt.zero_grad()
-        out = orc.train_step(P, buf, ob, eps_z, eps_z2, names, l2_reg=cfg.train.l2_reg,
-                             z_unit_ball_reg=1.0)
+        out = orc.train_step(P, buf, ob, torch.randn(n, zd), torch.randn(n, z2d), names,
+                             l2_reg=cfg.train.l2_reg, z_unit_ball_reg=1.0)
         out['loss'].backward()
         torch.nn.utils.clip_grad_norm_(params, 10.0)
         opt.step()
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {'value': n_traces / best, 'unit': 'traces/s', 'cores': threads, 'kind': 'port',
-            'sample': f'oracle train step (batch build + fwd + bwd + clip + RMSprop) on '
-                      f'{n_traces} traces of the same synthetic set (one bench batch), 1 timed step after 1 warm-up'}
+
+    def score_step(n, k):
+        ob = batch_of(n)
+        orc.eval_step(P, buf, ob, torch.randn(k, n, zd), torch.randn(k, n, z2d),
+                      latency_log_prob_weight=True)
+
+    out = {'unit': 'traces/s', 'cores': cores, 'threads': threads, 'kind': 'port'}
+    torch.set_num_threads(threads)
+    out['value'], t_train = _median_rate(lambda: train_step(64), 64, 2, 5)
+    if score_k > 0:
+        out['scoring_value'], t_score = _median_rate(lambda: score_step(4, score_k), 4, 1, 3)
+    torch.set_num_threads(1)
+    out['value_1_thread'], t_one = _median_rate(lambda: train_step(8), 8, 1, 3)
+    torch.set_num_threads(threads)
+    out['sample'] = (
+        f'oracle (fp32, stock CPU PyTorch ops) on traces of the same synthetic set: train step '
+        f'(batch build + fwd + bwd + clip + RMSprop) on 64 traces, 2 warm-up + 5 timed steps, '
+        f'median {1e3 * float(np.median(t_train)):.0f} ms, {threads} threads; one thread: 8 traces, '
+        f'1 + 3 steps, median {1e3 * float(np.median(t_one)):.0f} ms'
+        + (f'; scoring K={score_k} on 4 traces, 1 + 3 calls, median '
+           f'{1e3 * float(np.median(t_score)):.0f} ms' if score_k > 0 else ''))
+    return out
 
 
 def main():
@@ -210,7 +250,8 @@ def main():
         raise RuntimeError(f'non-finite training loss in the timed region: {loss_vals}')
 
     # ---- scoring leg (not part of `value`; reported next to it): every rank scores its own
-    # shard of traces, no communication; whole-job rate over all ranks
+    # shard of traces, no communication; whole-job rate over all ranks.
+    # BASELINE.json configs[3]: K = 100 samples per trace.
     scoring = None
     if args.score_k > 0:
         vae.eval()
@@ -221,11 +262,15 @@ def main():
                              latency_log_prob_weight=True, clip_nll=100_000.0)[1]
         score_one()
         barrier()
+        ops.TIMER.reset()
+        ops.TIMER.enabled = True
         ts = time.perf_counter()
         for _ in range(args.score_steps):
             score_one()
         barrier()
         dt = time.perf_counter() - ts
+        ops.TIMER.enabled = False
+        score_kernels = ops.TIMER.summary()
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64,
                              device=dev if dist.get_backend() == 'nccl' else 'cpu')
@@ -233,7 +278,28 @@ def main():
             dt = float(t.item())
         scoring = {'metric': 'nll_scoring_traces_per_sec',
                    'value': SB * world * args.score_steps / dt, 'unit': 'traces/s', 'n_z': K,
-                   'batch_per_gpu': SB, 'n_gpus': world, 'ms_per_step': 1e3 * dt / args.score_steps}
+                   'batch_per_gpu': SB, 'n_gpus': world, 'steps': args.score_steps,
+                   'ms_per_step': 1e3 * dt / args.score_steps,
+                   'workload': f'BASELINE.json configs[3]: K={K}-sample NLL scoring, {SB} traces '
+                               f'per call per GPU, decoders on K*B*M = {K * SB * M} rows'}
+        g = score_kernels.get('gemm_f32', (0, 0.0, 0.0))
+        if g[2] > 0:
+            tf = g[1] / (g[2] * 1e-3) / 1e12
+            scoring['roofline'] = {
+                'bound': 'mfma', 'kernel': GEMM_KERNEL, 'achieved': tf, 'peak': GEMM_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': tf / GEMM_PEAK_TFLOPS, 'traffic': None,
+                'launches': g[0], 'avg_ms': g[2] / max(g[0], 1), 'share_of_step': g[2] * 1e-3 / dt}
+            ideal = g[1] / (GEMM_PEAK_TFLOPS * 1e12)
+            a = score_kernels.get('gat_aggregate_fwd')
+            if a and a[2] > 0:
+                ideal += a[1] / (HBM_PEAK_GBS * 1e9)
+                scoring['gat_aggregate_fwd'] = {
+                    'bound': 'hbm', 'achieved': a[1] / (a[2] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': a[1] / (a[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'launches': a[0], 'avg_ms': a[2] / a[0], 'share_of_step': a[2] * 1e-3 / dt}
+            scoring['step_roofline'] = {'ideal_ms_per_step': 1e3 * ideal / args.score_steps,
+                                        'measured_ms_per_step': 1e3 * dt / args.score_steps,
+                                        'frac': ideal / dt}
 
     # ---- prior-sampling leg (section 8f row 4; N=1 only, not part of `value`): p() without
     # an observed graph, and the sampled-graph index kernels on their own against HBM
@@ -332,8 +398,7 @@ def main():
             'final_loss': float(loss_vals[-1]),
         }
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
-            threads = min(16, os.cpu_count() or 1)
-            line['cpu_baseline'] = cpu_baseline(cfg, flat, lr, V, M, args.cpu_baseline_traces, threads)
+            line['cpu_baseline'] = cpu_baseline(cfg, flat, lr, V, M, args.score_k)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

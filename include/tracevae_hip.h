@@ -422,6 +422,12 @@ int tv_normal_ll_bwd(int64_t rows, int64_t dim, const float *x, const float *mea
  * its forward call filled (same parameters).  A NULL entry of `grads` skips that tensor.
  * tv_realnvp_supported: kernels exist for dim 10 / 16 / 20 with hidden 64. */
 int tv_realnvp_supported(int dim, int hidden);
+/* Data-dependent initialisation of the ActNorm layers on the first batch (tensorkit ActNorm;
+ * the `initialize()` pass of train.py:188-199): level by level bias = -mean, pre_scale =
+ * -log(max(std, 1e-6)) of the level's input over the rows (biased variance), written into
+ * params[l*9 + 0] and params[l*9 + 1]; the other tensors are only read.  1 <= rows <= 1024. */
+int tv_realnvp_actnorm_init(int64_t rows, int levels, int dim, int hidden, float slope,
+                            const float *z, float *const *params, void *stream);
 int64_t tv_realnvp_workspace_floats(int64_t rows, int levels, int dim, int hidden);
 int tv_realnvp_logprob_fwd(int64_t rows, int levels, int dim, int hidden, float slope,
                            const float *z, const float *const *params, float *ws,

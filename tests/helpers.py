@@ -126,3 +126,39 @@ def golden_sample_flat():
     lr = TraceGraphLatencyRangeFile(
         latency_data={int(k): v for k, v in golden['latency_range'].items()})
     return flat, lr, golden['num_operations'], graphs
+
+
+def flow_log_prob_reference(flow, z, init_act_norm=False):
+    """log p(z) of an `InverseRealNVP` module written out with stock tensor ops (SURVEY.md
+    appendix B4; the same formulas as `oracle.model.OracleTraceVAE._flow_log_prob`), on the
+    module's own parameters so that autograd gives reference gradients.  `init_act_norm`:
+    first set every ActNorm from its input batch like tensorkit's data-dependent
+    initialisation does (bias = -mean, pre_scale = -log(max(std, 1e-6)), biased std)."""
+    import torch.nn.functional as F
+    lead = z.shape[:-1]
+    x = z.reshape(-1, z.shape[-1])
+    logdet = torch.zeros(x.shape[0], dtype=z.dtype, device=z.device)
+    flows = list(flow.original_flow.flows)
+    for lvl in range(len(flows) // 3):
+        an, cp, dense = flows[3 * lvl:3 * lvl + 3]
+        if init_act_norm:
+            with torch.no_grad():
+                an.bias.copy_(-x.mean(0))
+                an.pre_scale.copy_(-torch.log(x.std(0, unbiased=False).clamp(min=1e-6)))
+        x = (x + an.bias) * torch.exp(an.pre_scale)
+        logdet = logdet + an.pre_scale.sum()
+        n1 = cp.n1
+        x1, x2 = x[:, :n1], x[:, n1:]
+        br = cp.shift_and_pre_scale
+        h = x1
+        for lin in br.shared:
+            h = F.leaky_relu(F.linear(h, lin.weight_store.value, lin.bias_store.value), 0.01)
+        shift = F.linear(h, br.branches[0][0].weight_store.value, br.branches[0][0].bias_store.value)
+        pre = F.linear(h, br.branches[1][0].weight_store.value, br.branches[1][0].bias_store.value)
+        log_scale = F.logsigmoid(pre + 2.0)
+        x = torch.cat([x1, (x2 + shift) * torch.exp(log_scale)], dim=-1)
+        logdet = logdet + log_scale.sum(-1)
+        x = x @ dense.kernel.t()
+        logdet = logdet + torch.linalg.slogdet(dense.kernel)[1]
+    base = (-0.5 * float(np.log(2.0 * np.pi)) - 0.5 * x * x).sum(-1)
+    return (base + logdet).reshape(lead)

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import hand_made_flat, make_flat, oracle_batch, rel_err
+from helpers import flow_log_prob_reference, hand_made_flat, make_flat, oracle_batch, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -669,7 +669,6 @@ def _random_flow(dim, levels, seed, device):
 def test_realnvp_log_prob(device, dim, levels, rows):
     flow = _random_flow(dim, levels, 100 + rows, device)
     ref = _random_flow(dim, levels, 100 + rows, device).double()
-    assert flow._fused_params(dim) is not None
     gen = torch.Generator(device='cpu').manual_seed(rows)
     z = (1.5 * torch.randn(rows, dim, generator=gen)).to(device)
     w = torch.randn(rows, generator=gen).to(device)
@@ -677,7 +676,7 @@ def test_realnvp_log_prob(device, dim, levels, rows):
     lp = flow.log_prob(zf)
     (lp * w).sum().backward()
     zr = z.double().requires_grad_(True)
-    lp_ref = ref.log_prob_torch(zr)
+    lp_ref = flow_log_prob_reference(ref, zr)
     (lp_ref * w.double()).sum().backward()
     assert rel_err(lp, lp_ref) < 1e-4
     assert rel_err(zf.grad, zr.grad) < 1e-4
@@ -690,7 +689,7 @@ def test_realnvp_k_samples_frozen_parameters_and_fallback(device):
     flow = _random_flow(10, 5, 7, device)
     ref = _random_flow(10, 5, 7, device).double()
     z = torch.randn(3, 40, 10, device=device)
-    assert rel_err(flow.log_prob(z), ref.log_prob_torch(z.double())) < 1e-4   # [K, B] leading dims
+    assert rel_err(flow.log_prob(z), flow_log_prob_reference(ref, z.double())) < 1e-4   # [K, B] leading dims
     assert flow.log_prob(z).shape == (3, 40)
     # frozen parameters (phase 2 of training): only dz comes back
     for p in flow.parameters():
@@ -698,29 +697,66 @@ def test_realnvp_k_samples_frozen_parameters_and_fallback(device):
     zf = z.clone().requires_grad_(True)
     flow.log_prob(zf).sum().backward()
     zr = z.double().requires_grad_(True)
-    ref.log_prob_torch(zr).sum().backward()
+    flow_log_prob_reference(ref, zr).sum().backward()
     assert rel_err(zf.grad, zr.grad) < 1e-4
     assert all(p.grad is None for p in flow.parameters())
     # empty input
     assert flow.log_prob(torch.zeros(0, 10, device=device)).shape == (0,)
-    # a flow the kernel does not cover keeps the PyTorch formulation
+    # a flow the kernels do not cover is refused when it is built (one implementation only)
     from tracevae_amd.config import RealNVPFlowConfig
     from tracevae_amd.model import InverseRealNVP
-    cfg = RealNVPFlowConfig()
-    cfg.coupling_hidden_layer_units = 32
-    other = InverseRealNVP(10, cfg).to(device)
-    for m in other.modules():
-        if hasattr(m, 'initialized'):
-            m.initialized = True
-    assert other._fused_params(10) is None
-    assert other.log_prob(z).shape == (3, 40)
+    for field, value in (('coupling_hidden_layer_units', 32), ('coupling_hidden_layer_count', 2),
+                         ('coupling_layer_scale', 'exp'), ('flow_levels', 9)):
+        cfg = RealNVPFlowConfig()
+        setattr(cfg, field, value)
+        with pytest.raises(NotImplementedError):
+            InverseRealNVP(10, cfg)
+    with pytest.raises(NotImplementedError):
+        InverseRealNVP(12, RealNVPFlowConfig())
     # bad shapes are refused on the host
     from tracevae_amd import ops
-    params, levels, hidden = flow._fused_params(10)
+    params, levels, hidden = flow._kernel_params(), flow.levels, flow.hidden
     with pytest.raises(ValueError):
         ops.realnvp_log_prob(z, params[:-1], levels, hidden, 0.01)
     with pytest.raises(ValueError):
         ops.realnvp_log_prob(torch.randn(4, 10, device=device), [params[1]] + params[1:], 5, 32, 0.01)
+
+
+@pytest.mark.parametrize('dim,levels,rows', [(10, 5, 64), (10, 5, 1), (20, 3, 700), (16, 8, 1024)])
+def test_realnvp_actnorm_data_dependent_init(device, dim, levels, rows):
+    """The first batch initialises every ActNorm (tensorkit's data-dependent init, reference
+    train.py:188-199): `tv_realnvp_actnorm_init` against the level-by-level tensor formulation
+    in float64, and the log-density of that first batch."""
+    flow = _random_flow(dim, levels, 300 + rows, device)
+    ref = _random_flow(dim, levels, 300 + rows, device).double()
+    for f in (flow, ref):
+        for m in f.modules():
+            if hasattr(m, 'initialized'):
+                m.initialized = False
+    gen = torch.Generator(device='cpu').manual_seed(rows)
+    z = (2.0 * torch.randn(rows, dim, generator=gen) + 0.5).to(device)
+    with torch.no_grad():
+        lp = flow.log_prob(z)
+        lp_ref = flow_log_prob_reference(ref, z.double(), init_act_norm=True)
+    assert all(m.initialized for m in flow.modules() if hasattr(m, 'initialized'))
+    for (name, p), (_, q) in zip(flow.named_parameters(), ref.named_parameters()):
+        if name.endswith('.bias') and 'flows' in name or name.endswith('pre_scale'):
+            assert rel_err(p, q) < 1e-4, name
+    assert rel_err(lp, lp_ref) < 1e-4
+    # the second batch leaves them alone
+    before = [p.detach().clone() for p in flow.parameters()]
+    with torch.no_grad():
+        flow.log_prob(z[: max(rows // 2, 1)] * 3.0)
+    assert all(torch.equal(a, b) for a, b in zip(before, flow.parameters()))
+    # more rows than the one-workgroup kernel takes: a clear error
+    if rows == 64:
+        fresh = _random_flow(dim, levels, 1, device)
+        for m in fresh.modules():
+            if hasattr(m, 'initialized'):
+                m.initialized = False
+        from tracevae_amd import hip
+        with pytest.raises(hip.HipLibraryError):
+            fresh.log_prob(torch.randn(1025, dim, device=device))
 
 
 # ---------------------------------------------------------------------------------------

@@ -243,6 +243,63 @@ __global__ __launch_bounds__(64) void flow_fwd_kernel(int64_t rows, int levels, 
 }
 
 // ---------------------------------------------------------------------------------------
+// data-dependent initialisation of the ActNorm layers (tensorkit ActNorm on its first batch,
+// reference train.py:188-199: one forward pass on init_batch_size traces): level by level,
+// bias = -mean and pre_scale = -log(max(std, 1e-6)) of the level's INPUT over the batch (biased
+// variance, two passes in float64), then the level is applied with those values.  One
+// workgroup, a lane per row (rows <= 1024): the levels are sequential and the batch is tiny.
+template <int D, int H>
+__global__ __launch_bounds__(1024) void flow_actnorm_init_kernel(int rows, int levels, float slope,
+                                                                 const float *__restrict__ z,
+                                                                 FlowPtrs fp, FlowGradPtrs out) {
+  using L = LdsW<D, H>;
+  __shared__ __align__(16) float s_w[L::SIZE];
+  __shared__ double s_red[16][D];
+  __shared__ double s_mean[D];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool valid = t < rows;
+  float x[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) x[j] = valid ? z[(int64_t)t * D + j] : 0.f;
+  for (int l = 0; l < levels; ++l) {
+    __syncthreads();
+    stage_level<D, H, 1024>(fp.p[l], s_w, t);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const double v = tv_wave_sum_d(valid ? (double)x[j] : 0.0);
+      if (lane == 0) s_red[wave][j] = v;
+    }
+    __syncthreads();
+    if (t < D) {
+      double m = 0.0;
+      for (int w = 0; w < 16; ++w) m += s_red[w][t];
+      s_mean[t] = m / rows;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const double d = valid ? (double)x[j] - s_mean[j] : 0.0;
+      const double v = tv_wave_sum_d(d * d);
+      if (lane == 0) s_red[wave][j] = v;
+    }
+    __syncthreads();
+    if (t < D) {
+      double q = 0.0;
+      for (int w = 0; w < 16; ++w) q += s_red[w][t];
+      const float sd = (float)sqrt(q / rows);
+      const float bias = (float)(-s_mean[t]);
+      const float pre = -logf(fmaxf(sd, 1e-6f));
+      out.g[l][0][t] = bias;
+      out.g[l][1][t] = pre;
+      s_w[L::L_AB + t] = bias;
+      s_w[L::L_AS + t] = pre;
+    }
+    __syncthreads();
+    level_forward<D, H>(s_w, slope, x);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 constexpr int RS = 65;   // LDS row stride of the staging arrays (64 rows + 1: conflict-free)
 
 template <int D, int H>
@@ -503,6 +560,15 @@ int run_bwd(int64_t rows, int levels, float slope, const float *z, const FlowPtr
   return TV_OK;
 }
 
+template <int D, int H>
+int run_actnorm_init(int64_t rows, int levels, float slope, const float *z, const FlowPtrs &fp,
+                     const FlowGradPtrs &out, hipStream_t s) {
+  hipLaunchKernelGGL((flow_actnorm_init_kernel<D, H>), dim3(1), dim3(1024), 0, s, (int)rows, levels,
+                     slope, z, fp, out);
+  TV_LAUNCH_CHECK("tv_realnvp_actnorm_init");
+  return TV_OK;
+}
+
 }  // namespace
 
 extern "C" int tv_realnvp_supported(int dim, int hidden) {
@@ -548,4 +614,22 @@ extern "C" int tv_realnvp_logprob_bwd(int64_t rows, int levels, int dim, int hid
     for (int i = 0; i < NP; ++i) gp.g[l][i] = grads[l * NP + i];
   hipStream_t s = (hipStream_t)stream;
   TV_FLOW_DISPATCH(run_bwd, rows, levels, slope, z, fp, dlog_prob, ws, dz, gp, s);
+}
+
+extern "C" int tv_realnvp_actnorm_init(int64_t rows, int levels, int dim, int hidden, float slope,
+                                       const float *z, float *const *params, void *stream) {
+  if (int rc = check_dims("tv_realnvp_actnorm_init", rows, levels, dim, hidden)) return rc;
+  TV_REQUIRE(rows >= 1 && rows <= 1024,
+             "tv_realnvp_actnorm_init: the initialisation batch must hold 1..1024 rows, got %lld",
+             (long long)rows);
+  TV_REQUIRE(z, "tv_realnvp_actnorm_init: null pointer");
+  FlowPtrs fp{};
+  if (int rc = fill_ptrs("tv_realnvp_actnorm_init", levels, params, &fp)) return rc;
+  FlowGradPtrs out{};
+  for (int l = 0; l < levels; ++l) {
+    out.g[l][0] = params[l * NP + 0];
+    out.g[l][1] = params[l * NP + 1];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  TV_FLOW_DISPATCH(run_actnorm_init, rows, levels, slope, z, fp, out, s);
 }

@@ -340,19 +340,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   sb.init_act(g.act_scale, g.act_shift, g.act_slope, n0, g.N, kbeg);
   float *As = smem, *Bs = smem + 2 * TILE_FLOATS;
 
-  // where the operand prologue runs: after the multiply that follows the loads (default), or
-  // right before the LDS stores (-DTV_ACT_AT_STORE, kept for A/B measurements)
-#ifdef TV_ACT_AT_STORE
-#define TV_POST_LOAD()
-#define TV_PRE_STORE() do { sa.transform(); sb.transform(); } while (0)
-#else
+  // the operand prologue runs after the multiply that follows the loads
 #define TV_POST_LOAD() do { sa.transform(); sb.transform(); } while (0)
-#define TV_PRE_STORE()
-#endif
   if (nt > 0) {
     if (ntf > 0) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
     TV_POST_LOAD();
-    TV_PRE_STORE();
     sa.store(As);
     sb.store(Bs);
   }
@@ -367,7 +359,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   for (; it + 2 < ntf; ++it) {
     const int cur = it & 1;
     __syncthreads();
-    TV_PRE_STORE();
     sa.store(As + (cur ^ 1) * TILE_FLOATS);
     sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
     sa.advance(); sb.advance();
@@ -376,11 +367,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     // sinks them below the MFMAs (shorter live ranges) and the next iteration then waits for
     // them right after the barrier
     __builtin_amdgcn_sched_barrier(0);
-#if defined(TV_ACT_AT_STORE) || defined(TV_ACT_AFTER_MULTIPLY)
-    multiply_tile<A_KX, B_KX, true>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
-                                    lane, BK / 8, acc);
-    TV_POST_LOAD();
-#else
     // the prologue of tile t+2 (its loads were issued before this multiply) goes after the
     // third and fourth k-block, fenced so that it stays between the MFMA groups
     multiply_tile<A_KX, B_KX, true>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
@@ -392,15 +378,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
                                         __builtin_amdgcn_sched_barrier(0);
                                       }
                                     });
-#endif
   }
   // the last (up to three) tiles: stop staging, the partial k-tile goes through the masked path
   for (; it < nt; ++it) {
     const int cur = it & 1;
     __syncthreads();
     if (it + 1 < nt) {
-      TV_PRE_STORE();
-      sa.store(As + (cur ^ 1) * TILE_FLOATS);
+        sa.store(As + (cur ^ 1) * TILE_FLOATS);
       sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
     }
     if (it + 2 < nt) {
@@ -413,7 +397,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     if (it + 2 < nt) TV_POST_LOAD();
   }
 #undef TV_POST_LOAD
-#undef TV_PRE_STORE
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int kh = lane >> 5, xl = lane & 31;
@@ -433,7 +416,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   float *out = split ? (g.slabs + (int64_t)sp * g.M * g.N) : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
   const bool plain = split || (!g.row_scale && !g.accumulate);
-#ifndef TV_GEMM_DIRECT_EPILOGUE
   if (plain && g.c_vec && m0 + BM <= g.M) {
     // all 128 rows of the tile exist and rows can be written 16 bytes per lane: the wave
     // transposes its 64x64 block through LDS (the tile buffers are free now) and stores whole
@@ -466,7 +448,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     }
     return;
   }
-#endif
   if (plain && m0 + BM <= g.M) {
     // all 128 rows of the tile exist: stores are only predicated on the column of the lane
     float *o = out + (m0 + wm * 64 + 4 * kh) * ldo + n0 + wn * 64 + xl;

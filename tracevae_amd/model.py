@@ -15,12 +15,11 @@ signatures are the reference's):
 Module attribute names reproduce the reference's `state_dict()` keys (SURVEY.md appendix C;
 the tensorkit-side names are unverified there and collected in `checkpoint.KEY_NOTES`).
 
-What runs where: every operator on a `[rows, features]` tensor is a HIP kernel (`ops.py`).
-The 10-dimensional RealNVP prior and a handful of `[B]`-sized reductions stay in PyTorch
-("excluded from kernel scope").
+What runs where: every operator on a `[rows, features]` tensor is a HIP kernel (`ops.py`),
+the RealNVP prior included (`csrc/flow.hip`); a handful of `[B]`-sized index / reshape steps
+stay tensor ops.
 """
 import math
-import os
 from typing import Dict, List, Mapping, Optional
 
 import torch
@@ -37,15 +36,16 @@ __all__ = ['TraceVAE', 'TraceStructVAE', 'TraceLatencyVAE', 'OperationEmbedding'
 
 # tensorkit's BatchNorm epsilon (believed 1e-6, SURVEY.md appendix B3 - unverified)
 BN_EPSILON = 1e-6
-# latency decoder on compact rows (real nodes + one representative per trace); '0' keeps the
-# reference's padded [B*M] rows (A/B switch for tests and measurements)
-COMPACT_LATENCY_DECODER = os.environ.get('TRACEVAE_COMPACT_LATDEC', '1') != '0'
+# latency decoder on compact rows (real nodes + one representative per trace) wherever the
+# padded slots are provably identical; the padded [B*M] rows are the form for every other case
+# (observed node types that are not the batch's own, no latency mask).  A module constant, not a
+# run-time switch: the equivalence test patches it.
+COMPACT_LATENCY_DECODER = True
 LRELU_SLOPE = 0.01
-# the RealNVP prior as one HIP kernel per direction (0: the PyTorch formulation, for A/B runs)
-FUSED_PRIOR_FLOW = os.environ.get('TRACEVAE_FUSED_FLOW', '1') != '0'
 # training: BatchNorm + LeakyReLU between two GAT layers applied inside the next layer's GEMMs
-# instead of as a pass of its own (0: materialise every activation, for A/B runs)
-FUSED_BN_LINEAR = os.environ.get('TRACEVAE_FUSED_BN_LINEAR', '1') != '0'
+# instead of as a pass of its own (the materialised form serves the layers in front of a pooling
+# or GraphConv tail and eval mode; the equivalence test patches this constant)
+FUSED_BN_LINEAR = True
 
 
 # ---------------------------------------------------------------------------------------
@@ -342,25 +342,17 @@ def make_gnn_layers(gnn_cfg, input_dim: int, sizes: List[int]):
 
 
 # ---------------------------------------------------------------------------------------
-# RealNVP prior (10-dimensional; plain PyTorch, appendix B4)
+# RealNVP prior (realnvp_flow.py:18-49): parameters here, arithmetic in csrc/flow.hip
 # ---------------------------------------------------------------------------------------
 class ActNorm(nn.Module):
+    """tensorkit ActNorm: y = (x + bias) * exp(pre_scale); both are set from the first batch
+    (`tv_realnvp_actnorm_init`, driven by `InverseRealNVP.log_prob`)."""
+
     def __init__(self, dim: int):
         super().__init__()
         self.pre_scale = nn.Parameter(torch.zeros(dim))
         self.bias = nn.Parameter(torch.zeros(dim))
         self.initialized = False
-
-    def forward(self, x):
-        if not self.initialized:
-            # data-dependent initialisation on the first batch (train.py:188-199)
-            with torch.no_grad():
-                mean = x.mean(dim=0)
-                std = x.std(dim=0, unbiased=False)
-                self.bias.copy_(-mean)
-                self.pre_scale.copy_(-torch.log(std.clamp(min=1e-6)))
-            self.initialized = True
-        return (x + self.bias) * torch.exp(self.pre_scale), self.pre_scale.sum()
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
@@ -381,6 +373,8 @@ class _Branch(nn.Module):
         ])
 
     def forward(self, x1):
+        """shift and pre-scale of a few rows (only `InverseRealNVP.sample` comes here: drawing
+        from the prior runs the flow backwards, off the training / scoring path)."""
         h = x1
         for lin in self.shared:
             h = F.leaky_relu(F.linear(h, lin.weight_store.value, lin.bias_store.value), LRELU_SLOPE)
@@ -399,27 +393,12 @@ class CouplingLayer(nn.Module):
         self.shift_and_pre_scale = _Branch(self.n1, dim - self.n1, cfg.coupling_hidden_layer_count,
                                            cfg.coupling_hidden_layer_units)
 
-    def forward(self, x):
-        x1, x2 = x[:, :self.n1], x[:, self.n1:]
-        shift, pre = self.shift_and_pre_scale(x1)
-        if self.scale_type == 'sigmoid':
-            log_scale = F.logsigmoid(pre + 2.0)
-        elif self.scale_type == 'exp':
-            log_scale = pre
-        else:
-            raise NotImplementedError(self.scale_type)
-        y2 = (x2 + shift) * torch.exp(log_scale)
-        return torch.cat([x1, y2], dim=-1), log_scale.sum(-1)
-
 
 class InvertibleDense(nn.Module):
     def __init__(self, dim: int):
         super().__init__()
         q, _ = torch.linalg.qr(torch.randn(dim, dim))
         self.kernel = nn.Parameter(q.contiguous())
-
-    def forward(self, x):
-        return x @ self.kernel.t(), torch.linalg.slogdet(self.kernel)[1]
 
 
 class _SequentialFlow(nn.Module):
@@ -430,55 +409,58 @@ class _SequentialFlow(nn.Module):
 
 class InverseRealNVP(nn.Module):
     """`make_realnvp_flow(z_dim, cfg).invert()` used as a prior: `log_prob(z)` runs the
-    original flow forward (realnvp_flow.py:18-49, struct_vae.py:148-149, 251-254)."""
+    original flow forward (realnvp_flow.py:18-49, struct_vae.py:148-149, 251-254).  One
+    implementation: `tv_realnvp_logprob_*` (and `tv_realnvp_actnorm_init` for the first batch);
+    a flow shape those kernels do not cover is refused when the model is built."""
 
     def __init__(self, dim: int, cfg):
         super().__init__()
+        if cfg.coupling_layer_scale != 'sigmoid' or cfg.coupling_hidden_layer_count != 1 or \
+                not 1 <= cfg.flow_levels <= 8 or \
+                not ops.realnvp_supported(dim, cfg.coupling_hidden_layer_units, cfg.flow_levels):
+            raise NotImplementedError(
+                f'RealNVP prior with dim {dim}, {cfg.flow_levels} levels, '
+                f'{cfg.coupling_hidden_layer_count} hidden layer(s) of '
+                f'{cfg.coupling_hidden_layer_units} units and {cfg.coupling_layer_scale!r} scale: '
+                f'the accelerated path covers dim 10 / 16 / 20, 1-8 levels, ONE hidden layer of '
+                f'64 units and the sigmoid scale (the train.sh configuration)')
         flows = []
         for _ in range(cfg.flow_levels):
             flows += [ActNorm(dim), CouplingLayer(dim, cfg), InvertibleDense(dim)]
         self.original_flow = _SequentialFlow(flows)
+        self.levels = cfg.flow_levels
+        self.hidden = cfg.coupling_hidden_layer_units
 
-    def _fused_params(self, dim: int):
-        """The 9 tensors per level `tv_realnvp_logprob_fwd` takes, or None when this flow is not
-        the shape the kernel covers (then, and for the data-dependent ActNorm initialisation
-        of the first batch, the PyTorch formulation below runs)."""
+    def _kernel_params(self):
+        """The 9 tensors per level in the order of `tv_realnvp_logprob_fwd`."""
         flows = list(self.original_flow.flows)
-        levels = len(flows) // 3
-        if not FUSED_PRIOR_FLOW or levels == 0:
-            return None
         params = []
-        hidden = None
-        for lvl in range(levels):
+        for lvl in range(self.levels):
             an, cp, dense = flows[3 * lvl:3 * lvl + 3]
             br = cp.shift_and_pre_scale
-            if not an.initialized or cp.scale_type != 'sigmoid' or len(br.shared) != 1:
-                return None
-            h = br.shared[0].weight_store.value.shape[0]
-            if hidden is None:
-                hidden = h
-            if h != hidden:
-                return None
             params += [an.bias, an.pre_scale, br.shared[0].weight_store.value,
                        br.shared[0].bias_store.value,
                        br.branches[0][0].weight_store.value, br.branches[0][0].bias_store.value,
                        br.branches[1][0].weight_store.value, br.branches[1][0].bias_store.value,
                        dense.kernel]
-        if not ops.realnvp_supported(dim, hidden, levels):
-            return None
-        return params, levels, hidden
+        return params
 
     def log_prob(self, z: torch.Tensor) -> torch.Tensor:
-        fused = self._fused_params(z.shape[-1]) if z.is_cuda else None
-        if fused is not None:
-            params, levels, hidden = fused
-            return ops.realnvp_log_prob(z, params, levels, hidden, LRELU_SLOPE)
-        return self.log_prob_torch(z)
+        params = self._kernel_params()
+        act_norms = [m for m in self.original_flow.flows if isinstance(m, ActNorm)]
+        if not all(m.initialized for m in act_norms):
+            # the first batch sets bias / pre_scale of every level (train.py:188-199)
+            with torch.no_grad():
+                ops.realnvp_actnorm_init(z, params, self.levels, self.hidden, LRELU_SLOPE)
+            for m in act_norms:
+                m.initialized = True
+        return ops.realnvp_log_prob(z, params, self.levels, self.hidden, LRELU_SLOPE)
 
     def sample(self, eps: torch.Tensor) -> torch.Tensor:
         """z = flow(eps) of `FlowDistribution(UnitNormal, original_flow.invert())`
         (struct_vae.py:251-254): the original flow run backwards, level by level.  A few
-        10-dimensional rows, off the hot path: PyTorch, the dense inverse in float64."""
+        10-dimensional rows per prior-sampling call (section 8f row 4, not the training /
+        scoring path): tensor ops, the dense inverse in float64."""
         lead = eps.shape[:-1]
         x = eps.reshape(-1, eps.shape[-1])
         for flow in reversed(list(self.original_flow.flows)):
@@ -488,29 +470,13 @@ class InverseRealNVP(nn.Module):
             elif isinstance(flow, CouplingLayer):
                 y1, y2 = x[:, :flow.n1], x[:, flow.n1:]
                 shift, pre = flow.shift_and_pre_scale(y1)
-                if flow.scale_type == 'sigmoid':
-                    log_scale = F.logsigmoid(pre + 2.0)
-                elif flow.scale_type == 'exp':
-                    log_scale = pre
-                else:
-                    raise NotImplementedError(flow.scale_type)
-                x = torch.cat([y1, y2 * torch.exp(-log_scale) - shift], dim=-1)
+                x = torch.cat([y1, y2 * torch.exp(-F.logsigmoid(pre + 2.0)) - shift], dim=-1)
             else:
                 if not flow.initialized:
                     raise RuntimeError('the prior flow has not been initialised: train or '
                                        'load a model before sampling from it')
                 x = x * torch.exp(-flow.pre_scale) - flow.bias
         return x.reshape(lead + (x.shape[-1],))
-
-    def log_prob_torch(self, z: torch.Tensor) -> torch.Tensor:
-        lead = z.shape[:-1]
-        x = z.reshape(-1, z.shape[-1])
-        logdet = torch.zeros(x.shape[0], device=z.device, dtype=z.dtype)
-        for flow in self.original_flow.flows:
-            x, ld = flow(x)
-            logdet = logdet + ld
-        base = (-0.5 * math.log(2.0 * math.pi) - 0.5 * x * x).sum(-1)
-        return (base + logdet).reshape(lead)
 
 
 # ---------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ __all__ = [
     'DeviceGraph', 'TIMER', 'gemm', 'linear', 'matmul_nn', 'rowdot', 'colsum', 'gat_conv', 'bn_lrelu', 'bn_lrelu_linear',
     'graph_sum', 'segment_mean', 'embedding', 'latdec_input', 'latdec_rows', 'adj_bernoulli_ll',
     'categorical_ll', 'normal_reparam', 'normal_ll', 'realnvp_log_prob', 'realnvp_supported',
+    'realnvp_actnorm_init',
     'latency_ll', 'score_reduce',
     'LATENCY_MODES',
 ]
@@ -911,6 +912,19 @@ class _RealNVPLogProb(Function):
             hip.call('tv_realnvp_logprob_bwd', rows, levels, dim, hidden, slope, hip.ptr(z), table,
                      hip.ptr(dlogp), hip.ptr(ws), hip.ptr(dz), gtable)
         return (dz if ctx.needs_input_grad[0] else None, None, None, None) + tuple(grads)
+
+
+def realnvp_actnorm_init(z, params, levels: int, hidden: int, slope: float) -> None:
+    """Data-dependent ActNorm initialisation on the first batch (`tv_realnvp_actnorm_init`):
+    writes bias / pre_scale of every level in place."""
+    import ctypes
+    z = _check(z.detach().reshape(-1, z.shape[-1]), 'z')
+    params = [_check(p.detach(), 'flow parameter') for p in params]
+    if len(params) != 9 * levels:
+        raise ValueError(f'expected {9 * levels} flow parameters, got {len(params)}')
+    table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+    hip.call('tv_realnvp_actnorm_init', z.shape[0], levels, z.shape[1], hidden, float(slope),
+             hip.ptr(z), table)
 
 
 def realnvp_supported(dim: int, hidden: int, levels: int) -> bool:

@@ -30,10 +30,6 @@ from .batch import DeviceTraceStore, TraceGraphBatch
 from .config import ExpConfig, config_to_dict
 from .model import TraceVAE
 
-# the scalar end of the step (loss / recons / kl and their gradients) as one kernel each way;
-# TRACEVAE_FUSED_LOSS=0 composes it from tensor ops instead (same numbers)
-FUSED_TRAIN_LOSS = os.environ.get('TRACEVAE_FUSED_LOSS', '1') != '0'
-
 __all__ = ['NANLossError', 'FlatParameters', 'FlatOptimizer', 'compute_train_loss', 'Trainer',
            'l2_parameter_names', 'learning_rate_for_epoch', 'save_model', 'StoreStream', 'fit',
            'run_training', 'run_with_nan_restart', 'init_distributed', 'all_reduce_sum',
@@ -186,18 +182,11 @@ class FlatOptimizer(object):
                  float(b1), float(b2), float(self.eps), self.steps)
 
 
-def _unit_ball(loss, t, reg):
-    """train.py:259-266 with get_moments(t, axis=[-1]) (tensor_utils.py:117-125)."""
-    if reg is not None:
-        m = t.mean(-1)
-        v = (t * t).mean(-1) - m * m
-        loss = loss + reg * ((m * m).mean() + ((v - 1) ** 2).mean())
-    return loss
-
-
 def compute_train_loss(chain, train_cfg, l2_value: Optional[torch.Tensor] = None,
                        epoch: Optional[int] = None) -> Dict[str, torch.Tensor]:
-    """The loss of `train_step` (train.py:229-270) given the chain `q(G).chain(p, G=G)`."""
+    """The loss of `train_step` (train.py:229-270) given the chain `q(G).chain(p, G=G)`:
+    recons, kl, beta * kl - recons + L2 + the unit-ball regularisers (train.py:259-270 with
+    get_moments, tensor_utils.py:117-125) - one kernel each way (`csrc/loss.hip`)."""
     p_obs, p_latent, q_latent = [], [], []
     for name in chain.p:
         if name in chain.q:
@@ -209,27 +198,18 @@ def compute_train_loss(chain, train_cfg, l2_value: Optional[torch.Tensor] = None
     if train_cfg.warm_up_epochs and epoch is not None and epoch < train_cfg.warm_up_epochs:
         beta = beta * (epoch / train_cfg.warm_up_epochs)
     z = chain.q['z'].tensor
-    if FUSED_TRAIN_LOSS and z.is_cuda and z.dim() == 2 and \
-            len(p_obs) + len(q_latent) + len(p_latent) <= 8:
-        # the whole scalar end of the step in one kernel each way (csrc/loss.hip)
-        latents = []
-        if train_cfg.z_unit_ball_reg is not None:
-            latents.append((z, train_cfg.z_unit_ball_reg))
-        if 'z2' in chain.q and train_cfg.z2_unit_ball_reg is not None:
-            latents.append((chain.q['z2'].tensor, train_cfg.z2_unit_ball_reg))
-        use_l2 = bool(train_cfg.l2_reg) and l2_value is not None
-        loss, recons, kl = ops.train_loss(
-            p_obs, q_latent, p_latent, beta, l2_value.reshape(1) if use_l2 else None,
-            train_cfg.l2_reg if use_l2 else 0.0, latents)
-        return {'loss': loss, 'recons': recons, 'kl': kl}
-    recons = sum(p_obs[1:], p_obs[0]).mean()
-    kl = (sum(q_latent[1:], q_latent[0]) - sum(p_latent[1:], p_latent[0])).mean()
-    loss = beta * kl - recons
-    if train_cfg.l2_reg and l2_value is not None:
-        loss = loss + train_cfg.l2_reg * l2_value
-    loss = _unit_ball(loss, chain.q['z'].tensor, train_cfg.z_unit_ball_reg)
-    if 'z2' in chain.q:
-        loss = _unit_ball(loss, chain.q['z2'].tensor, train_cfg.z2_unit_ball_reg)
+    if z.dim() != 2:
+        raise ValueError('the training loss takes one sample per trace (q(G) without n_z): z is '
+                         f'{tuple(z.shape)}')
+    latents = []
+    if train_cfg.z_unit_ball_reg is not None:
+        latents.append((z, train_cfg.z_unit_ball_reg))
+    if 'z2' in chain.q and train_cfg.z2_unit_ball_reg is not None:
+        latents.append((chain.q['z2'].tensor, train_cfg.z2_unit_ball_reg))
+    use_l2 = bool(train_cfg.l2_reg) and l2_value is not None
+    loss, recons, kl = ops.train_loss(
+        p_obs, q_latent, p_latent, beta, l2_value.reshape(1) if use_l2 else None,
+        train_cfg.l2_reg if use_l2 else 0.0, latents)
     return {'loss': loss, 'recons': recons, 'kl': kl}
 
 
