@@ -86,6 +86,25 @@ def test_edge_topologies(device):
     _compare(flat, lr, 30, M, ids=[4, 0, 5, 0, 2, 5])     # repeats and reordering
 
 
+def test_edge_lists_that_are_not_in_bfs_order(device):
+    """graph_vectors() emits edges grouped by parent in BFS order; any valid edge list (u < v)
+    must still give the stable sort by destination (the general rank path of the kernel)."""
+    from tracevae_amd.data import FlatTraces
+    flat, lr = hand_made_flat([[0, 0, 1, 1, 2, 2, 3], [0, 1, 1, 1, 2, 5], [0] * 9], 30, seed=6)
+    rng = np.random.RandomState(4)
+    u, v = flat.u.copy(), flat.v.copy()
+    for i in range(len(flat)):                         # shuffle the edges of every trace
+        e0, e1 = int(flat.node_offsets[i]) - i, int(flat.node_offsets[i + 1]) - i - 1
+        perm = e0 + rng.permutation(e1 - e0)
+        u[e0:e1], v[e0:e1] = flat.u[perm], flat.v[perm]
+    assert not np.array_equal(v, flat.v)
+    shuffled = FlatTraces(node_offsets=flat.node_offsets, u=u, v=v, node_type=flat.node_type,
+                          avg_latency=flat.avg_latency, max_latency=flat.max_latency,
+                          min_latency=flat.min_latency, labels=flat.labels)
+    _compare(shuffled, lr, 30, 12)
+    _compare(shuffled, lr, 30, 300)                    # the four-wave launch
+
+
 def test_large_max_node_count(device):
     flat, lr = make_flat(8, 500, 100, seed=2)
     _compare(flat, lr, 500, 100)

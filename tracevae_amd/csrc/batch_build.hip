@@ -1,6 +1,6 @@
 // (a) batching: trace store in HBM -> batched COO + destination-sorted CSC + observed
-// tensors.  One wave per trace; the per-trace index work happens in LDS, the outputs are
-// written once, coalesced.  HBM-bound integer work: ~ (24 B in + 16*E_enc + 16*E_dec +
+// tensors.  One workgroup per trace; the per-trace index work happens in LDS (per-edge
+// parallel, O(n)), the outputs are written once, coalesced.  HBM-bound integer work: ~ (24 B in + 16*E_enc + 16*E_dec +
 // 8*(N + B*M) + observed tensors) per batch.
 //
 // Reference behaviour restated (see include/tracevae_hip.h for the call sites):
@@ -34,17 +34,34 @@ __device__ __forceinline__ float normalize_latency(float x, double mu, double sd
   return (float)(((double)x - mu) / (sd + 1e-5));
 }
 
-// LDS layout (int32): u[M] v[M] indptr[M+1] nbr[3M] eid[3M]
-__global__ __launch_bounds__(64) void batch_build_kernel(BatchArgs a) {
+// One workgroup per trace (64 lanes for short traces, 256 for long ones); per-EDGE parallel
+// index work in LDS, O(n) in all:
+//   in-edges of node x in edge-id order = [e with v[e] == x ; e with u[e] == x ; self], so the CSC
+//   position of edge e is   pA = indptr[v] + rankA(e)            (the entry "u -> v" in v's list)
+//                           pB = indptr[u] + cntA[u] + rankB(e)  (the entry "v -> u" in u's list)
+//   with cntA / cntB the per-node counts (integer LDS atomics: order-free sums) and rankA / rankB
+//   the rank of e among the earlier edges with the same v / u.  The two entries are each other's
+//   reverse: rev[pA] = pB, rev[pB] = pA - no search.
+//   graph_vectors() emits edges in BFS order (trace_graph.py:286-352): v strictly increasing, u
+//   non-decreasing; then rankA = 0 and rankB = e - (first edge of u).  Any other order of a valid
+//   edge list takes the general ranks (a count over the earlier edges).
+// LDS (int32): u[M] v[M] indptr[M+1] cntA[M] cntB[M] first[M] nbr[3M] eid[3M] rev[3M]
+constexpr int BB_LDS_INTS_PER_NODE = 15;
+
+__global__ __launch_bounds__(256) void batch_build_kernel(BatchArgs a) {
   extern __shared__ int32_t lds[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const int64_t i = blockIdx.x;
   const int64_t M = a.M;
   int32_t *su = lds;
   int32_t *sv = su + M;
   int32_t *sptr = sv + M;
-  int32_t *snbr = sptr + (M + 1);
+  int32_t *scA = sptr + (M + 1);
+  int32_t *scB = scA + M;
+  int32_t *sfirst = scB + M;
+  int32_t *snbr = sfirst + M;
   int32_t *seid = snbr + 3 * M;
+  int32_t *srev = seid + 3 * M;
 
   const int64_t n0 = a.node_offsets[i];
   const int64_t n64 = a.node_offsets[i + 1] - n0;
@@ -56,7 +73,7 @@ __global__ __launch_bounds__(64) void batch_build_kernel(BatchArgs a) {
   // Compact latency-decoder graph = encoder graph + one self-loop node per trace (row N + i)
   // standing for the trace's M - n padded slots: the caller sized the encoder arrays, node_type
   // and graph_id with B more entries.
-  if (a.lat_row_weight && lane == 0) {
+  if (a.lat_row_weight && tid == 0) {
     const int64_t Et = 3 * a.N - 2 * a.B, p = Et + i, row = a.N + i;
     a.enc_src[p] = row; a.enc_dst[p] = row;
     a.enc_indices[p] = row; a.enc_eids[p] = p; a.enc_rev[p] = p;
@@ -66,9 +83,9 @@ __global__ __launch_bounds__(64) void batch_build_kernel(BatchArgs a) {
     a.lat_row_weight[row] = (n64 >= 1 && n64 <= M) ? (float)(M - n64) : 0.f;
   }
   if (n64 < 1 || n64 > M) {
-    if (lane == 0) atomicOr(a.status, TV_BATCH_TOO_MANY_NODES);
+    if (tid == 0) atomicOr(a.status, TV_BATCH_TOO_MANY_NODES);
     // keep the decoder structure of this slot well-formed (self loops only)
-    for (int64_t x = lane; x < M; x += 64) {
+    for (int64_t x = tid; x < M; x += nth) {
       a.dec_indptr[dbase + x] = D0 + x;
     }
     return;
@@ -78,21 +95,22 @@ __global__ __launch_bounds__(64) void batch_build_kernel(BatchArgs a) {
   const int64_t sn = a.store_node_start[i];
   const int64_t se = a.store_edge_start[i];
 
-  // ---- edges into LDS + validation
+  // ---- edges into LDS + validation; per-node counters cleared
   int bad = 0;
-  for (int e = lane; e < ne; e += 64) {
+  for (int e = tid; e < ne; e += nth) {
     int64_t u = a.store_u[se + e], v = a.store_v[se + e];
     if (!(u >= 0 && u < v && v < n)) { bad = 1; u = 0; v = 1; }
     su[e] = (int32_t)u;
     sv[e] = (int32_t)v;
   }
+  for (int x = tid; x < n; x += nth) { scA[x] = 0; scB[x] = 0; sfirst[x] = 0x7fffffff; }
   if (__syncthreads_or(bad)) {
-    if (lane == 0) atomicOr(a.status, TV_BATCH_BAD_EDGE);
+    if (tid == 0) atomicOr(a.status, TV_BATCH_BAD_EDGE);
   }
 
   // ---- node features, pads
   int flags = 0;
-  for (int x = lane; x < n; x += 64) {
+  for (int x = tid; x < n; x += nth) {
     const int64_t t = a.store_node_type[sn + x];
     a.node_type[n0 + x] = t;
     a.graph_id[n0 + x] = i;
@@ -116,11 +134,12 @@ __global__ __launch_bounds__(64) void batch_build_kernel(BatchArgs a) {
     a.latency_pad[dbase + x] = la;
   }
   if (flags) atomicOr(a.status, flags);
-  if (lane == 0) a.node_count[i] = n;
+  if (tid == 0) a.node_count[i] = n;
 
-  // ---- COO (edge-id order) + observed adjacency
+  // ---- COO (edge-id order) + observed adjacency; degree counts; is the list in BFS order?
   const int64_t T = M * (M - 1) / 2;
-  for (int e = lane; e < ne; e += 64) {
+  int unordered = 0;
+  for (int e = tid; e < ne; e += nth) {
     const int64_t u = su[e], v = sv[e];
     a.enc_src[E0 + e] = n0 + u;           a.enc_dst[E0 + e] = n0 + v;
     a.enc_src[E0 + ne + e] = n0 + v;      a.enc_dst[E0 + ne + e] = n0 + u;
@@ -128,81 +147,81 @@ __global__ __launch_bounds__(64) void batch_build_kernel(BatchArgs a) {
     a.dec_src[D0 + ne + e] = dbase + v;   a.dec_dst[D0 + ne + e] = dbase + u;
     // strict upper triangle, row-major: row u starts at u*(2M-u-1)/2  (tensor_utils.py:60-67)
     a.adj[i * T + u * (2 * M - u - 1) / 2 + (v - u - 1)] = 1.0f;
+    atomicAdd(&scA[v], 1);
+    atomicAdd(&scB[u], 1);
+    atomicMin(&sfirst[u], e);
+    if (e > 0 && (sv[e - 1] >= v || su[e - 1] > u)) unordered = 1;
   }
-  for (int x = lane; x < n; x += 64) {
+  for (int x = tid; x < n; x += nth) {
     a.enc_src[E0 + 2 * ne + x] = n0 + x;
     a.enc_dst[E0 + 2 * ne + x] = n0 + x;
   }
-  for (int64_t x = lane; x < M; x += 64) {
+  for (int64_t x = tid; x < M; x += nth) {
     a.dec_src[D0 + 2 * ne + x] = dbase + x;
     a.dec_dst[D0 + 2 * ne + x] = dbase + x;
   }
+  unordered = __syncthreads_or(unordered);
 
-  // ---- in-degree of every node, then an exclusive scan (wave scan in chunks of 64)
-  int carry = 0;
-  for (int base = 0; base < n; base += 64) {
-    const int x = base + lane;
-    int deg = 0;
-    if (x < n) {
-      deg = 1;  // self loop
-      for (int e = 0; e < ne; ++e) deg += (sv[e] == x) + (su[e] == x);
-    }
-    int incl = deg;
+  // ---- exclusive scan of the in-degrees (wave 0, chunks of 64)
+  if (tid < 64) {
+    int carry = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int x = base + lane;
+      const int deg = x < n ? scA[x] + scB[x] + 1 : 0;
+      int incl = deg;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (x < n) sptr[x] = carry + incl - deg;
+      carry += __shfl(incl, 63, 64);
     }
-    if (x < n) sptr[x] = carry + incl - deg;
-    carry += __shfl(incl, 63, 64);
-  }
-  if (lane == 0) sptr[n] = carry;  // == 3n-2
-  __syncthreads();
-
-  // ---- fill: in-edges of x in edge-id order = [u->x edges ; child->x edges ; self]
-  for (int x = lane; x < n; x += 64) {
-    int p = sptr[x];
-    for (int e = 0; e < ne; ++e)
-      if (sv[e] == x) { snbr[p] = su[e]; seid[p] = e; ++p; }
-    for (int e = 0; e < ne; ++e)
-      if (su[e] == x) { snbr[p] = sv[e]; seid[p] = ne + e; ++p; }
-    snbr[p] = x;
-    seid[p] = 2 * ne + x;
+    if (lane == 0) sptr[n] = carry;  // == 3n-2
   }
   __syncthreads();
 
-  // ---- CSC out (encoder and decoder share the local structure)
-  for (int x = lane; x < n; x += 64) {
+  // ---- fill, one edge per lane: both CSC entries of the edge and their reverse links
+  for (int e = tid; e < ne; e += nth) {
+    const int u = su[e], v = sv[e];
+    int rA = 0, rB = e - sfirst[u];
+    if (unordered) {
+      rB = 0;
+      for (int f = 0; f < e; ++f) { rA += sv[f] == v; rB += su[f] == u; }
+    }
+    const int pA = sptr[v] + rA, pB = sptr[u] + scA[u] + rB;
+    snbr[pA] = u; seid[pA] = e;      srev[pA] = pB;
+    snbr[pB] = v; seid[pB] = ne + e; srev[pB] = pA;
+  }
+  for (int x = tid; x < n; x += nth) {
+    const int p = sptr[x + 1] - 1;   // the self loop closes the row
+    snbr[p] = x; seid[p] = 2 * ne + x; srev[p] = p;
     a.enc_indptr[n0 + x] = E0 + sptr[x];
     a.dec_indptr[dbase + x] = D0 + sptr[x];
   }
-  for (int64_t x = n + lane; x < M; x += 64) {
+  for (int64_t x = n + tid; x < M; x += nth) {
     const int64_t p = D0 + (3 * (int64_t)n - 2) + (x - n);
     a.dec_indptr[dbase + x] = p;
     a.dec_indices[p] = dbase + x;
     a.dec_eids[p] = D0 + 2 * ne + x;
     a.dec_rev[p] = p;
   }
-  if (last && lane == 0) {
+  if (last && tid == 0) {
     a.enc_indptr[a.N] = E0 + 3 * (int64_t)n - 2;
     a.dec_indptr[a.B * M] = D0 + 2 * (int64_t)ne + M;
   }
-  for (int x = lane; x < n; x += 64) {
-    const int p0 = sptr[x], p1 = sptr[x + 1];
-    for (int p = p0; p < p1; ++p) {
-      const int s = snbr[p];
-      // position of the opposite edge (x -> s) inside the in-edge list of s
-      int q = sptr[s];
-      const int q1 = sptr[s + 1];
-      while (q < q1 && snbr[q] != x) ++q;
-      if (q >= q1) q = p;  // cannot happen for a symmetric graph
-      a.enc_indices[E0 + p] = n0 + s;
-      a.enc_eids[E0 + p] = E0 + seid[p];
-      a.enc_rev[E0 + p] = E0 + q;
-      a.dec_indices[D0 + p] = dbase + s;
-      a.dec_eids[D0 + p] = D0 + seid[p];
-      a.dec_rev[D0 + p] = D0 + q;
-    }
+  __syncthreads();
+
+  // ---- CSC out (encoder and decoder share the local structure), one entry per lane
+  const int np = 3 * n - 2;
+  for (int p = tid; p < np; p += nth) {
+    const int s = snbr[p], id = seid[p], q = srev[p];
+    a.enc_indices[E0 + p] = n0 + s;
+    a.enc_eids[E0 + p] = E0 + id;
+    a.enc_rev[E0 + p] = E0 + q;
+    a.dec_indices[D0 + p] = dbase + s;
+    a.dec_eids[D0 + p] = D0 + id;
+    a.dec_rev[D0 + p] = D0 + q;
   }
 }
 
@@ -259,8 +278,18 @@ extern "C" int tv_batch_build(
   a.adj = adj; a.node_type_pad = node_type_pad; a.latency_pad = latency_pad;
   a.node_count = node_count; a.node_type = node_type; a.latency = latency;
   a.graph_id = graph_id; a.lat_row_weight = lat_row_weight; a.status = status;
-  const size_t lds_bytes = sizeof(int32_t) * (size_t)(2 * M + (M + 1) + 6 * M);
-  hipLaunchKernelGGL(batch_build_kernel, dim3((unsigned)batch), dim3(64), lds_bytes, s, a);
+  const size_t lds_bytes = sizeof(int32_t) * (size_t)(BB_LDS_INTS_PER_NODE * M + 1);
+  if (lds_bytes > 64 * 1024) {
+    static bool raised = false;          // per process
+    if (!raised) {
+      TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&batch_build_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised = true;
+    }
+  }
+  // long traces get four waves per trace, short ones one
+  const unsigned threads = M > 128 ? 256 : 64;
+  hipLaunchKernelGGL(batch_build_kernel, dim3((unsigned)batch), dim3(threads), lds_bytes, s, a);
   TV_LAUNCH_CHECK("tv_batch_build");
   return TV_OK;
 }
