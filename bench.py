@@ -27,13 +27,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, fp32 matrix (dense)
-GEMM_KERNEL = 'gemm_f32_kernel'
-GEMM_PEAK_TFLOPS = F32_MFMA_PEAK_TFLOPS
+# The GEMM multiplies fp32 operands as three bf16 pieces each, six bf16 partial products per
+# algorithmic product, fp32 accumulation (csrc/gemm_f32.hip).  Its matrix-core ceiling in
+# algorithmic (2*M*N*K) flops is the dense bf16 peak of MI355X_MICROARCH.md over six.
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+GEMM_KERNEL = 'gemm_kernel'
+GEMM_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+GEMM_DTYPE = 'f32 via bf16x3 split, 6 terms, fp32 accumulate'
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per GEMM launch of the default workload, from the committed --pmc passes
 # (tools/summarize_profile.py traffic; FETCH_SIZE x2 + WRITE_SIZE, separate passes)
-TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r01k_hbm_traffic.json')
+TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
 
 
 def measured_traffic(args):
@@ -340,10 +344,12 @@ def main():
         roof = None
         if g[2] > 0:
             tf = g[1] / (g[2] * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel', 'achieved': tf,
-                    'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': tf / F32_MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(args),
-                    'traffic_unit': 'bytes/launch (profiles/r01k_hbm_traffic.json)',
+            roof = {'bound': 'mfma', 'kernel': GEMM_KERNEL, 'achieved': tf,
+                    'peak': GEMM_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'peak_is': 'dense bf16 MFMA peak (2500 TFLOP/s) / 6 partial products; achieved '
+                               'counts algorithmic 2*M*N*K flops',
+                    'frac': tf / GEMM_PEAK_TFLOPS, 'traffic': measured_traffic(args),
+                    'traffic_unit': 'bytes/launch (profiles/r02_hbm_traffic.json)',
                     'launches': g[0], 'avg_ms': g[2] / max(g[0], 1),
                     'share_of_step': g[2] * 1e-3 / elapsed}
             # the same figure for the shapes that carry the time (the aggregate above also
@@ -353,7 +359,7 @@ def main():
                 {'m': t[0], 'n': t[1], 'k': t[2], 'trans_a': t[3], 'trans_b': t[4],
                  'launches_per_step': c / args.steps, 'ms_per_step': ms / args.steps,
                  'achieved': w / (ms * 1e-3) / 1e12,
-                 'frac': w / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+                 'frac': w / (ms * 1e-3) / 1e12 / GEMM_PEAK_TFLOPS}
                 for t, (c, w, ms) in tags]
         others = {}
         for name in ('gat_aggregate_fwd', 'gat_aggregate_bwd'):
@@ -367,7 +373,7 @@ def main():
         # ideal time (flops / MFMA peak, or algorithmic bytes / HBM peak) over the measured step;
         # kernels without a work model count as zero ideal time, so this is a lower bound
         ideal_s = attributed_ms = 0.0
-        for name, peak in (('gemm_f32', F32_MFMA_PEAK_TFLOPS * 1e12),
+        for name, peak in (('gemm_f32', GEMM_PEAK_TFLOPS * 1e12),
                            ('gat_aggregate_fwd', HBM_PEAK_GBS * 1e9),
                            ('gat_aggregate_bwd', HBM_PEAK_GBS * 1e9)):
             if name in kernel_summary:
@@ -377,7 +383,7 @@ def main():
                      'measured_ms_per_step': 1e3 * elapsed / args.steps,
                      'frac': ideal_s / elapsed,
                      'attributed_share_of_step': attributed_ms * 1e-3 / elapsed,
-                     'covers': 'gemm_f32 against the fp32 MFMA peak, gat_aggregate_fwd/bwd against '
+                     'covers': 'gemm_f32 against bf16 MFMA peak / 6, gat_aggregate_fwd/bwd against '
                                'HBM; every other kernel counts as zero ideal time (lower bound). '
                                'The step is compute-dominated: the HBM figures refer to the '
                                'message-passing kernels only'}
@@ -385,7 +391,7 @@ def main():
             'metric': 'train_step_traces_per_sec', 'value': value, 'unit': 'traces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': GEMM_DTYPE, 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[1]: synthetic traces <=100 spans, '
                                    '1k-op vocab, default TraceVAE dims (train.sh flags), '
                                    'MAX_NODE_COUNT=100, training step',

@@ -138,8 +138,12 @@ int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int64_t num_ed
 
 /* ------------------------------------------------------------------------------------
  * dense layers: C[M,N] = row_scale[m] * (op(A)[M,K] . op(B)[K,N]) + bias[n]
- * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
- * row-major storage; transX = 0: stored as written, 1: stored transposed.
+ * fp32 in / fp32 out, fp32-accurate: each operand element is split into three bf16 pieces and
+ * the six partial products of weight >= 2^-16 are accumulated in fp32 on
+ * v_mfma_f32_32x32x16_bf16 (no other precision exists; the error against float64 is below that
+ * of an fp32 fma chain, tests/test_gpu_ops.py::test_gemm_error_against_float64...).  An
+ * infinite operand element gives NaN where an fp32 chain gives inf.
+ * row-major storage; transX = 0: stored as written, 1: stored transposed.  lda, ldb < 2^22.
  *
  * Replaces nn.Linear inside dgl.nn.GATConv.fc (model/gnn_layers.py:134-143), the matmul
  * of dgl.nn.GraphConv (gnn_layers.py:173-183), tk.layers.Linear / Dense

@@ -316,8 +316,11 @@ def test_compact_latency_decoder_equals_padded(device, monkeypatch, training):
     if training:
         assert set(a['grads']) == set(b['grads'])
         gmax = max(float(v.abs().max()) for v in b['grads'].values())
+        # The floor is for gradients that are zero in exact arithmetic (a GraphConv bias in front
+        # of a BatchNorm): both paths return rounding noise there, about 1e-7 of the largest
+        # gradient, and its value depends on the order of summation.
         for n, want in b['grads'].items():
-            scale = max(float(want.abs().max()), 1e-4 * gmax)
+            scale = max(float(want.abs().max()), 1e-3 * gmax)
             assert float((a['grads'][n] - want).abs().max()) / scale < 1e-3, n
 
 

@@ -56,6 +56,63 @@ def test_gemm_split_k_and_accumulate(device):
     assert rel_err(c, c0 + scale[:, None] * ref) < TOL
 
 
+def _gemm_error_inputs(kind, m, n, k, gen):
+    """Operand pairs for the accuracy bound of the split-bf16 GEMM, A [m, k] and B [n, k]."""
+    a = torch.randn(m, k, generator=gen, dtype=torch.float64)
+    b = torch.randn(n, k, generator=gen, dtype=torch.float64)
+    if kind == 'wide':                      # 26 binary orders of magnitude inside one dot product
+        a = a * torch.exp2(torch.randint(-13, 14, (m, k), generator=gen).double())
+        b = b * torch.exp2(torch.randint(-13, 14, (n, k), generator=gen).double())
+    elif kind == 'cancelling':              # every dot product is a small difference of large sums
+        half = k // 2
+        a[:, half:2 * half] = a[:, :half]
+        b[:, half:2 * half] = -b[:, :half] * (1 + 1e-3 * torch.randn(n, half, generator=gen, dtype=torch.float64))
+    elif kind == 'positive':                # no cancellation: the accumulators only grow
+        a, b = a.abs(), b.abs()
+    elif kind == 'graded':                  # ill-conditioned operands: geometrically graded columns
+        grade = torch.logspace(0, -7, k, dtype=torch.float64)
+        a = a * grade
+        b = b / grade.flip(0) * 1e-7
+    elif kind == 'activations':             # what the layers feed it: post-LeakyReLU x small weights
+        a = torch.nn.functional.leaky_relu(a + 0.5, 0.01)
+        b = b * 0.03
+    return a.float(), b.float()
+
+
+@pytest.mark.parametrize('kind', ['normal', 'wide', 'cancelling', 'positive', 'graded', 'activations'])
+@pytest.mark.parametrize('m,n,k,ta,tb', [(512, 1000, 1000, False, True),      # layer forward
+                                          (512, 1000, 1000, False, False),     # input gradient
+                                          (384, 500, 20000, True, False)])     # weight gradient
+def test_gemm_error_against_float64_is_within_twice_an_fp32_gemm(device, kind, m, n, k, ta, tb):
+    """The GEMM multiplies on the bf16 matrix cores after splitting every fp32 operand into three
+    bf16 pieces (six partial products, fp32 accumulation: csrc/gemm_f32.hip).  Its error against
+    the float64 product of the same fp32 operands must not exceed twice that of an fp32 GEMM
+    (torch's, rocBLAS / hipBLASLt on fp32 matrix instructions), element-wise scaled by
+    sum_k |a||b| (the quantity a rounding-error bound is proportional to), and in the worst
+    result element relative to the largest result - on layer shapes, for well- and
+    ill-conditioned operands.  A small absolute floor (2^-24, half an fp32 ulp of the scale)
+    covers the cases where the fp32 GEMM happens to be exact."""
+    from tracevae_amd import ops
+    gen = torch.Generator().manual_seed(m + n + k + len(kind))
+    a, b = _gemm_error_inputs(kind, m, n, k, gen)           # A [m, k], B [n, k]
+    A, B = a.to(device), b.to(device)
+    exact = A.double() @ B.double().t()
+    scale = A.double().abs() @ B.double().abs().t()
+    a_arg = A.t().contiguous() if ta else A
+    b_arg = B if tb else B.t().contiguous()
+    got = ops.gemm(a_arg, b_arg, ta, tb).double()
+    ref = (A @ B.t()).double()
+    err_got = ((got - exact).abs() / scale).max().item()
+    err_ref = ((ref - exact).abs() / scale).max().item()
+    assert err_got <= 2 * err_ref + 2.0 ** -24, (kind, err_got, err_ref)
+    top = exact.abs().max().item()
+    worst_got = (got - exact).abs().max().item() / top
+    worst_ref = (ref - exact).abs().max().item() / top
+    assert worst_got <= 2 * worst_ref + 2.0 ** -24, (kind, worst_got, worst_ref)
+    print(f'{kind:12s} {m}x{n}x{k} ta={ta} tb={tb}: scaled {err_got:.2e} (fp32 GEMM {err_ref:.2e}), '
+          f'worst/top {worst_got:.2e} ({worst_ref:.2e})')
+
+
 def test_gemm_asymmetric_identity(device):
     """A = I with an asymmetric B catches a transposed accumulator layout."""
     from tracevae_amd import ops

@@ -1,27 +1,41 @@
-// Dense layers on the fp32 matrix cores of gfx950.
+// Dense layers on the matrix cores of gfx950: fp32 operands, fp32 result, fp32-accurate.
 //
-//   C[M,N] = row_scale[m] * (op(A)[M,K] . op(B)[K,N]) + bias[n]      (fp32 in, fp32 accumulate)
+//   C[M,N] = row_scale[m] * (op(A)[M,K] . op(B)[K,N]) + bias[n]
 //
-// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain, which is what the 1e-4 parity bound on
-// losses / scores needs (no reduced-precision path is used).
+// Every fp32 operand element is split into three bf16 planes x = x0 + x1 + x2 (round-to-nearest
+// at each level: 8 + 8 + 8 mantissa bits), and the six partial products of weight >= 2^-16,
+//     a0 b0 | a0 b1 + a1 b0 | a0 b2 + a1 b1 + a2 b0,
+// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate of
+// v_mfma_f32_32x32x2_f32, so 16/6 = 2.7x per product).  bf16 products are exact in fp32; a0 b0
+// goes to one accumulator and the five correction terms to a second one, added once at the end,
+// so the large accumulator is rounded once per 16-deep k-step (63 times at K = 1000 against
+// 1000 times in an fp32 fma chain).  Measured on MI355X against float64 the result is 2-4x
+// CLOSER than the exact-fp32 MFMA chain on normal, wide-dynamic-range, cancelling and
+// all-positive data (tools/bf16x3_numerics.hip; tests/test_gpu_ops.py holds the bound against
+// an fp32 GEMM; the dropped terms a1 b2, a2 b1, a2 b2 are below 2^-24 relative).  There is no
+// three-term variant and no other precision: this is the one GEMM of the library.  An infinite
+// operand gives NaN (inf - inf in the split) where an fp32 chain gives inf; NaN stays NaN.
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave owns a
-// 64x64 block = 2x2 MFMA tiles of 32x32 -> 64 accumulator registers), BK = 32, two workgroups
-// per CU.  An operand tile is staged in LDS in the orientation it has in memory, so staging is
-// a 16-byte load and a 16-byte LDS store with no transposition:
-//   row-major ([x][k] storage): LDS [x][k], row stride 36 floats; a lane's MFMA operands for one
-//     8-deep k-block are ONE ds_read_b128 (4 consecutive k of its row, conflict-free at stride 36)
-//   k-major ([k][x] storage):   LDS [k][x], row stride 132 floats; one ds_read_b32 per k-step
-// In both, lanes 0-31 hold k = 8*kb + s and lanes 32-63 hold k = 8*kb + 4 + s for step s of
-// k-block kb: an MFMA step multiplies that k pair (a fixed summation order, the same for A and B).
-// Pipeline (one barrier per tile): barrier; write the registers holding tile t+1 into the other
-// LDS buffer; issue the global loads of tile t+2; multiply tile t.  Loads therefore have a whole
-// tile of matrix work to land, and the LDS stores sit behind the first MFMAs of the tile.
+// Tiling: 128x128 output tile, BK = 32, one 512-thread workgroup per CU:
+//   waves 0-3  CONSUMERS, 2x2, each owns a 64x64 block = 2x2 MFMA tiles of 32x32, twice (the two
+//              accumulators) -> 128 accumulator registers; per k-tile 24 ds_read_b128 feed 48 MFMAs
+//   waves 4-7  PRODUCERS: global loads two tiles ahead -> operand prologue -> split -> the bf16
+//              planes of the next tile into the other LDS buffer
+// One of each kind sits on every SIMD, so the matrix pipe of a SIMD is fed by a wave that does
+// nothing else and its vector ALU by another; one workgroup barrier per k-tile hands the buffers
+// over.  The tile of each operand is three bf16 planes [x][k] (64-byte rows), the 16-byte chunk
+// index XOR-ed with (x >> 2) & 3, which makes the fragment reads (one ds_read_b128 = 8
+// consecutive k of a row) and the staging writes (ds_write_b64 = 4 consecutive k of a row, per
+// plane) conflict-free for k-contiguous operands and 2-way for x-contiguous ones.  A producer
+// thread owns 4 rows x 4 consecutive k of each operand:
+//   [x][k] storage: row (t>>3) + 32a, k = 4(t&7) .. +3   (one 16-byte load, or four 4-byte loads)
+//   [k][x] storage: row (t&31) + 32a, k = 4(t>>5) .. +3  (four 4-byte loads, 128 B per half-wave)
 // Edges: out-of-range rows/columns read a clamped (valid) address and only ever reach
 // accumulators that are not stored; the one partial k-tile is loaded through a masked path.
 // Workgroup ids are remapped so that the workgroups sharing an XCD (ids equal mod 8) walk a
 // contiguous range of tiles, n fastest: an A panel is then fetched into one L2 only.
-// Bound: MFMA (157.3 TFLOP/s fp32 dense peak); algorithmic flops = 2*M*N*K.
+// Bound: MFMA.  Algorithmic flops = 2*M*N*K; the matrix pipe executes six bf16 products per
+// algorithmic one, so the peak of this path is the dense bf16 peak / 6 = 2500 / 6 = 417 TFLOP/s.
 //
 // A reduction over many rows into a small output (weight gradients: M,N ~ 1000, K = rows)
 // is split over K into slabs and summed by a second kernel in slab order (deterministic).
@@ -31,9 +45,6 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int SX = 36;                        // row stride of an [x][k] tile (floats)
-constexpr int SK = 132;                       // row stride of a [k][x] tile
-constexpr int TILE_FLOATS = (BM * SX > BK * SK) ? BM * SX : BK * SK;  // one operand, one buffer
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -59,346 +70,13 @@ struct GemmArgs {
   float act_slope;
 };
 
-// Staging of one operand tile: 128 (x) by 32 (k) floats, 16 floats per thread.
-//   KX  = the operand is stored [k][x] (x contiguous), else [x][k] (k contiguous)
-//   VEC = 16-B loads (needs ld % 4 == 0, 16-B aligned base, contiguous extent % 4 == 0),
-//         else 4-B loads (any ld / alignment)
-// thread -> element maps (x, k local to the tile):
-//   [x][k] VEC:    float4 it: x = (t>>3) + 32*it, k = (t&7)*4 ..+3
-//   [k][x] VEC:    float4 it: k = (t>>5) + 8*it,  x = (t&31)*4 ..+3
-//   [x][k] scalar: element i: x = (t>>5) + 8*i,   k = t&31
-//   [k][x] scalar: element i: k = (t>>7) + 2*i,   x = t&127
-//   ACT = the operand goes through lrelu(v * scale[f] + shift[f]) before it is stored to LDS;
-//         f = k for an [x][k] operand (scale/shift follow the k-tiles), f = x for a [k][x] one
-//         (fixed per thread).  Elements of the zero-filled part of a partial k-tile stay zero
-//         for f = k; for f = x they become lrelu(shift), harmless because the other operand's
-//         zero-filled k rows multiply them.
-template <bool KX, bool VEC, bool ACT>
-struct Stage {
-  static constexpr int NL = VEC ? 4 : 16;
-  static constexpr int NF = VEC ? 4 : 1;      // features a thread touches
-  float r[16];
-  float sc[NF], sh[NF];
-  const float *act_scale, *act_shift;
-  float slope;
-  unsigned fpos;                              // feature index of this thread's first element
-  // element offset of load i from the tile origin = min(off0 + i*step, offmax): consecutive
-  // loads of a thread are `step` apart (a multiple of ld), and offmax clamps an out-of-range x
-  // (rows of an [x][k] operand) onto the last valid row -- such an x only feeds accumulators
-  // that are never stored, it just has to read a valid element
-  unsigned off0, offmax, step;
-  const float *tile;  // origin of the current tile (wave-uniform)
-  int64_t ld;
-  int t;
-
-  __device__ __forceinline__ int klocal(int i) const {
-    if (VEC) return KX ? (t >> 5) + 8 * i : (t & 7) * 4;
-    return KX ? (t >> 7) + 2 * i : (t & 31);
-  }
-  __device__ __forceinline__ int xlocal(int i) const {
-    if (VEC) return KX ? (t & 31) * 4 : (t >> 3) + 32 * i;
-    return KX ? (t & 127) : (t >> 5) + 8 * i;
-  }
-  __device__ __forceinline__ unsigned offset(int i) const {
-    const unsigned o = off0 + (unsigned)i * step;
-    return KX ? o : (o < offmax ? o : offmax);
-  }
-
-  __device__ __forceinline__ void init(const float *base, int64_t ld_, int64_t x0, int64_t xlim,
-                                       int64_t k0, int t_) {
-    ld = ld_; t = t_;
-    tile = KX ? base + k0 * ld + x0 : base + x0 * ld + k0;
-    if (KX) {
-      int x = xlocal(0);
-      if (x0 + x + (VEC ? 3 : 0) >= xlim) x = VEC ? 0 : (int)(xlim - 1 - x0);
-      off0 = (unsigned)(klocal(0) * ld + x);
-      step = (unsigned)((VEC ? 8 : 2) * ld);
-      offmax = 0xffffffffu;
-    } else {
-      off0 = (unsigned)(xlocal(0) * ld + klocal(0));
-      step = (unsigned)((VEC ? 32 : 8) * ld);
-      offmax = (unsigned)((xlim - 1 - x0) * ld + klocal(0));
-    }
-  }
-
-  __device__ __forceinline__ void init_act(const float *scale, const float *shift, float slope_,
-                                           int64_t x0, int64_t xlim, int64_t k0) {
-    if (!ACT) return;
-    act_scale = scale; act_shift = shift; slope = slope_;
-    if (KX) {
-      // the features are this thread's columns: the same (clamped) x as in init()
-      int x = xlocal(0);
-      if (x0 + x + (VEC ? 3 : 0) >= xlim) x = VEC ? 0 : (int)(xlim - 1 - x0);
-      fpos = (unsigned)(x0 + x);
-      load_act(NF);
-    } else {
-      fpos = (unsigned)(k0 + klocal(0));
-    }
-  }
-
-  // scale / shift of features fpos .. fpos+NF-1; the first `valid` of them exist
-  __device__ __forceinline__ void load_act(int valid) {
-    if (VEC && valid >= NF) {
-      const float4 a = *reinterpret_cast<const float4 *>(act_scale + fpos);
-      const float4 b = *reinterpret_cast<const float4 *>(act_shift + fpos);
-      sc[0] = a.x; sc[NF > 1 ? 1 : 0] = a.y; sc[NF > 2 ? 2 : 0] = a.z; sc[NF > 3 ? 3 : 0] = a.w;
-      sh[0] = b.x; sh[NF > 1 ? 1 : 0] = b.y; sh[NF > 2 ? 2 : 0] = b.z; sh[NF > 3 ? 3 : 0] = b.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const bool ok = j < valid;
-        sc[j] = ok ? act_scale[fpos + j] : 0.f;
-        sh[j] = ok ? act_shift[fpos + j] : 0.f;
-      }
-    }
-  }
-
-  __device__ __forceinline__ void advance() {
-    tile += KX ? BK * ld : BK;
-    if (ACT && !KX) fpos += BK;
-  }
-
-  // a full k-tile: unconditional loads
-  __device__ __forceinline__ void load() {
-    if (ACT && !KX) load_act(NF);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      if (VEC) {
-        const float4 v = *reinterpret_cast<const float4 *>(tile + offset(i));
-        r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
-      } else {
-        r[i] = tile[offset(i)];
-      }
-    }
-  }
-
-  // the partial last k-tile: k >= rem reads the tile's first k instead and is zeroed
-  __device__ __forceinline__ void load_tail(int rem) {
-    if (ACT && !KX) load_act(rem - klocal(0));
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int kl = klocal(i);
-      const bool ok = kl < rem;
-      const unsigned o = ok ? offset(i) : offset(i) - (KX ? (unsigned)(kl * ld) : (unsigned)kl);
-      if (VEC) {
-        const float4 v = *reinterpret_cast<const float4 *>(tile + o);
-        r[4 * i] = ok ? v.x : 0.f; r[4 * i + 1] = ok ? v.y : 0.f;
-        r[4 * i + 2] = ok ? v.z : 0.f; r[4 * i + 3] = ok ? v.w : 0.f;
-      } else {
-        const float v = tile[o];
-        r[i] = ok ? v : 0.f;
-      }
-    }
-  }
-
-  // lrelu(y) = max(y, slope*y) for 0 <= slope <= 1 (checked on the host): three VALU ops per
-  // element, written on float2 so that the fma and the multiply become packed-math instructions
-  __device__ __forceinline__ void act2(float &a, float &b, int ja, int jb) const {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 v = {a, b};
-    const f32x2 s2 = {sc[ja], sc[jb]}, h2 = {sh[ja], sh[jb]};
-    const f32x2 y = v * s2 + h2;
-    const f32x2 ys = y * slope;
-    a = fmaxf(y.x, ys.x);
-    b = fmaxf(y.y, ys.y);
-  }
-
-  // the prologue, in registers.  Called after the multiply that follows the loads, so that the
-  // arithmetic sits in the shadow of the MFMAs instead of between the barrier and the LDS stores
-  __device__ __forceinline__ void transform() {
-    transform_half(0);
-    transform_half(1);
-  }
-  __device__ __forceinline__ void transform_half(int h) {
-    if (!ACT) return;
-#pragma unroll
-    for (int i = 8 * h; i < 8 * h + 8; i += 2)
-      act2(r[i], r[i + 1], VEC ? (i & 3) : 0, VEC ? ((i + 1) & 3) : 0);
-  }
-
-  __device__ __forceinline__ void store(float *s) const {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int pos = KX ? klocal(i) * SK + xlocal(i) : xlocal(i) * SX + klocal(i);
-      if (VEC) *reinterpret_cast<float4 *>(&s[pos]) = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
-      else s[pos] = r[i];
-    }
-  }
-};
-
-// MFMA operands of k-block kb for the two 32-wide sub-tiles of a wave: f[sub][step]
-template <bool KX>
-__device__ __forceinline__ void read_fragments(const float *s, int w64, int lane, int kb,
-                                               float (&f)[2][4]) {
-  const int xl = lane & 31, kh = lane >> 5;
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
-    if (!KX) {
-      const float4 v = *reinterpret_cast<const float4 *>(&s[(w64 + sub * 32 + xl) * SX + 8 * kb + 4 * kh]);
-      f[sub][0] = v.x; f[sub][1] = v.y; f[sub][2] = v.z; f[sub][3] = v.w;
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) f[sub][q] = s[(8 * kb + 4 * kh + q) * SK + w64 + sub * 32 + xl];
-    }
-  }
-}
-
-// acc += A-tile . B-tile over `nkb` k-blocks of 8 (FULL: all four, fragments of block kb+1 are
-// read while block kb is multiplied)
-struct NoHook {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-
-// `hook(kb)` runs after the MFMAs of k-block kb have been issued (the steady-state loop puts the
-// operand prologue of the tile in flight there, in the shadow of the MFMA pipeline)
-template <bool A_KX, bool B_KX, bool FULL, typename Hook = NoHook>
-__device__ __forceinline__ void multiply_tile(const float *as, const float *bs, int wm64, int wn64,
-                                              int lane, int nkb, f32x16 (&acc)[2][2],
-                                              Hook hook = Hook()) {
-  float fa[2][2][4], fb[2][2][4];
-  read_fragments<A_KX>(as, wm64, lane, 0, fa[0]);
-  read_fragments<B_KX>(bs, wn64, lane, 0, fb[0]);
-#pragma unroll
-  for (int kb = 0; kb < BK / 8; ++kb) {
-    if (!FULL && kb >= nkb) break;
-    const int c = kb & 1;
-    if (kb + 1 < BK / 8 && (FULL || kb + 1 < nkb)) {
-      read_fragments<A_KX>(as, wm64, lane, kb + 1, fa[c ^ 1]);
-      read_fragments<B_KX>(bs, wn64, lane, kb + 1, fb[c ^ 1]);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][s], fb[c][0][s], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][s], fb[c][1][s], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][0][s], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][s], fb[c][1][s], acc[1][1], 0, 0, 0);
-    }
-    hook(kb);
-  }
-}
-
-// ACT: 0 = plain, 1 = prologue on A (row-major, !A_KX), 2 = prologue on B (k-major, B_KX)
-template <bool A_KX, bool B_KX, bool A_VEC, bool B_VEC, int ACT = 0>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
-  static_assert(ACT == 0 || (ACT == 1 && !A_KX) || (ACT == 2 && B_KX), "prologue orientation");
-  __shared__ __align__(16) float smem[4 * TILE_FLOATS];  // A0 A1 B0 B1
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = t >> 6;
+// Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// `smem` = the (now free) plane buffers: they hold a whole 64x64 block per consumer wave
+// (4 x 64 x 72 floats = 72 KB of the 96).
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2][2], float *smem,
+                                              int tile, int sp, bool tail, int nwg, int64_t m0,
+                                              int64_t n0, int wave, int lane) {
   const int wm = wave >> 1, wn = wave & 1;
-
-  // Workgroup id -> (output tile, k-split).  Ids below `remapped` are permuted so that the
-  // workgroups sharing an XCD (ids equal mod 8) walk a contiguous range of tiles, n fastest
-  // (bijective for any count); the tail-split units keep dispatch order so that the last,
-  // small units spread over all XCDs.  Everything here is wave-uniform: keep it in SGPRs.
-  const int tail_units = g.tail_splits > 1;
-  const int nwg = tail_units ? (int)g.tail_first : (int)gridDim.x;
-  const int bid = blockIdx.x;
-  int tile, sp;
-  int64_t kchunk;
-  const bool tail = tail_units && bid >= nwg;
-  if (tail) {
-    const int u = bid - nwg;
-    tile = nwg + u / (int)g.tail_splits;
-    sp = u % (int)g.tail_splits;
-    kchunk = g.tail_kchunk;
-  } else {
-    const int q = nwg >> 3, rr = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-    const int tiles = (int)(g.tiles_n * g.tiles_m);
-    tile = L % tiles;
-    sp = L / tiles;
-    kchunk = g.k_chunk;
-  }
-  tile = __builtin_amdgcn_readfirstlane(tile);
-  sp = __builtin_amdgcn_readfirstlane(sp);
-  const int tn = __builtin_amdgcn_readfirstlane(tile % (int)g.tiles_n);
-  const int tm = __builtin_amdgcn_readfirstlane(tile / (int)g.tiles_n);
-
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-  const int64_t kbeg = sp * kchunk;
-  const int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
-  const int64_t klen = kend > kbeg ? kend - kbeg : 0;
-  const int ntf = __builtin_amdgcn_readfirstlane((int)(klen / BK));          // full k-tiles
-  const int rem = __builtin_amdgcn_readfirstlane((int)(klen - (int64_t)ntf * BK));
-  const int nt = ntf + (rem ? 1 : 0);
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  Stage<A_KX, A_VEC, ACT == 1> sa;
-  Stage<B_KX, B_VEC, ACT == 2> sb;
-  sa.init(g.A, g.lda, m0, g.M, kbeg, t);
-  sb.init(g.B, g.ldb, n0, g.N, kbeg, t);
-  sa.init_act(g.act_scale, g.act_shift, g.act_slope, m0, g.M, kbeg);
-  sb.init_act(g.act_scale, g.act_shift, g.act_slope, n0, g.N, kbeg);
-  float *As = smem, *Bs = smem + 2 * TILE_FLOATS;
-
-  // the operand prologue runs after the multiply that follows the loads
-#define TV_POST_LOAD() do { sa.transform(); sb.transform(); } while (0)
-  if (nt > 0) {
-    if (ntf > 0) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
-    TV_POST_LOAD();
-    sa.store(As);
-    sb.store(Bs);
-  }
-  if (nt > 1) {
-    sa.advance(); sb.advance();
-    if (ntf > 1) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
-    TV_POST_LOAD();
-  }
-
-  // steady state: tiles t, t+1 and t+2 are all full k-tiles, nothing is conditional
-  int it = 0;
-  for (; it + 2 < ntf; ++it) {
-    const int cur = it & 1;
-    __syncthreads();
-    sa.store(As + (cur ^ 1) * TILE_FLOATS);
-    sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
-    sa.advance(); sb.advance();
-    sa.load(); sb.load();
-    // keep the loads of tile t+2 ahead of the multiply of tile t: left alone, the scheduler
-    // sinks them below the MFMAs (shorter live ranges) and the next iteration then waits for
-    // them right after the barrier
-    __builtin_amdgcn_sched_barrier(0);
-    // the prologue of tile t+2 (its loads were issued before this multiply) goes after the
-    // third and fourth k-block, fenced so that it stays between the MFMA groups
-    multiply_tile<A_KX, B_KX, true>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
-                                    lane, BK / 8, acc, [&](int kb) {
-                                      if (ACT != 0 && kb >= 2) {
-                                        __builtin_amdgcn_sched_barrier(0);
-                                        sa.transform_half(kb - 2);
-                                        sb.transform_half(kb - 2);
-                                        __builtin_amdgcn_sched_barrier(0);
-                                      }
-                                    });
-  }
-  // the last (up to three) tiles: stop staging, the partial k-tile goes through the masked path
-  for (; it < nt; ++it) {
-    const int cur = it & 1;
-    __syncthreads();
-    if (it + 1 < nt) {
-        sa.store(As + (cur ^ 1) * TILE_FLOATS);
-      sb.store(Bs + (cur ^ 1) * TILE_FLOATS);
-    }
-    if (it + 2 < nt) {
-      sa.advance(); sb.advance();
-      if (it + 2 < ntf) { sa.load(); sb.load(); } else { sa.load_tail(rem); sb.load_tail(rem); }
-    }
-    // only the k-blocks (8 deep) that hold data: all four, fewer in the partial tile
-    multiply_tile<A_KX, B_KX, false>(As + cur * TILE_FLOATS, Bs + cur * TILE_FLOATS, wm * 64, wn * 64,
-                                     lane, it < ntf ? BK / 8 : (rem + 7) >> 3, acc);
-    if (it + 2 < nt) TV_POST_LOAD();
-  }
-#undef TV_POST_LOAD
-
-  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int kh = lane >> 5, xl = lane & 31;
   if (tail) {
     float *slab = g.tail_slabs + ((int64_t)(tile - nwg) * g.tail_splits + sp) * (BM * BN);
@@ -423,27 +101,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     // Row stride 72 floats: the two 32-lane halves of an accumulator register (rows r, r+4)
     // land 32 banks apart.
     constexpr int ES = 72;
-    static_assert(4 * 64 * ES <= 4 * TILE_FLOATS, "epilogue staging fits the tile buffers");
-    __syncthreads();                                // every wave is done with the last k-tile
-    float *ws = smem + wave * (64 * ES);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ws[(i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * ES + j * 32 + xl] = acc[i][j][r];
+    constexpr int ROWS = 64;
+    float *ws = smem + wave * (ROWS * ES);          // (the caller's barrier freed the tile buffers)
     const int c = (lane & 15) * 4;
     const int64_t col = n0 + wn * 64 + c;
-    if (col < g.N) {                                // N % 4 == 0: the four columns exist together
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!split && g.bias) bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
-      float *o = out + (m0 + wm * 64 + (lane >> 4)) * ldo + col;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < g.N && !split && g.bias)
+      bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
+    {
+      constexpr int half = 0;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float4 v = *reinterpret_cast<const float4 *>(&ws[(q * 4 + (lane >> 4)) * ES + c]);
-        *reinterpret_cast<float4 *>(o + (int64_t)q * 4 * ldo) =
-            make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+      for (int i = 0; i < ROWS / 32; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            ws[(i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * ES + j * 32 + xl] = acc[i][j][r];
+      if (col < g.N) {                              // N % 4 == 0: the four columns exist together
+        float *o = out + (m0 + wm * 64 + half * ROWS + (lane >> 4)) * ldo + col;
+#pragma unroll
+        for (int q = 0; q < ROWS / 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4 *>(&ws[(q * 4 + (lane >> 4)) * ES + c]);
+          *reinterpret_cast<float4 *>(o + (int64_t)q * 4 * ldo) =
+              make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+        }
       }
     }
     return;
@@ -493,6 +174,376 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
       }
     }
   }
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+constexpr int PLANE_BYTES = BM * 64;            // one bf16 plane of one operand tile: 128 rows x 64 B
+constexpr int OPERAND_BYTES = 3 * PLANE_BYTES;  // 24 KB
+static_assert(BK == 32 && BM == BN, "plane layout assumes 32-deep tiles of 128 rows");
+
+__device__ __forceinline__ unsigned plane_offset(int row, int piece) {   // piece = 8-byte unit 0..7
+  return (unsigned)(row * 64 + ((((piece >> 1) ^ (row >> 2)) & 3) << 4) + ((piece & 1) << 3));
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {        // v_cvt_pk_bf16_f32
+  const f32x2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The 16 fp32 elements a producer thread holds of one operand tile: element (row a, k j).
+// They are the destinations of global loads issued with inline assembly, so that the loads of
+// two tiles stay in flight across the loop: the compiler's own counting of outstanding loads
+// merges the loop's paths and ends up waiting for the newest load before every split, which
+// exposes the whole memory latency once per k-tile.  Nothing may read a set between its loads
+// and the `landed()` that follows the matching s_waitcnt.
+template <int MODE>
+struct TileRegs {                                // 4-byte loads: one register per element
+  float v[16];
+  __device__ __forceinline__ float get(int a, int j) const { return v[4 * a + j]; }
+  __device__ __forceinline__ void set(int a, int j, float x) { v[4 * a + j] = x; }
+  __device__ __forceinline__ void landed() {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                      "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+  }
+};
+template <>
+struct TileRegs<0> {                             // 16-byte loads: one register quad per row
+  f32x4 q[4];
+  __device__ __forceinline__ float get(int a, int j) const { return q[a][j]; }
+  __device__ __forceinline__ void set(int a, int j, float x) { q[a][j] = x; }
+  __device__ __forceinline__ void landed() {
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void wait_loads_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
+
+// MODE 0: [x][k] storage, 16-byte loads; 1: [x][k], 4-byte loads; 2: [k][x], 4-byte loads.
+template <int MODE, bool ACT>
+struct Split {
+  static constexpr int LOADS = MODE == 0 ? 4 : 16;     // load instructions per tile and thread
+  using Regs = TileRegs<MODE == 0 ? 0 : 1>;
+  const char *tile;             // origin of the current k-tile (wave-uniform: stays in SGPRs)
+  unsigned off[4];              // BYTE offset of row a's first k (MODE 2: of column a at the
+                                // thread's first k) from `tile`
+  unsigned kstep;               // MODE 2: ld in bytes
+  int t, krow;                  // krow = first k of this thread inside the tile
+  // prologue: lrelu(v * scale[f] + shift[f]); f = k for MODE 0/1 (A), f = x for MODE 2 (B)
+  const float *act_scale, *act_shift;
+  float slope;
+  float sc[4], sh[4];           // MODE 2: fixed per thread; MODE 0/1: of the tile being split
+  unsigned fpos;                // MODE 0/1: first k of the first tile
+
+  __device__ __forceinline__ int row(int a) const { return MODE == 2 ? (t & 31) + 32 * a : (t >> 3) + 32 * a; }
+  __device__ __forceinline__ int piece() const { return MODE == 2 ? (t >> 5) : (t & 7); }
+
+  __device__ __forceinline__ void init(const float *base, int64_t ld, int64_t x0, int64_t xlim,
+                                       int64_t k0, int t_) {
+    t = t_;
+    krow = 4 * piece();
+    tile = reinterpret_cast<const char *>(MODE == 2 ? base + k0 * ld + x0 : base + x0 * ld + k0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int64_t x = row(a);
+      if (x0 + x >= xlim) x = xlim - 1 - x0;       // clamped rows only reach unstored accumulators
+      off[a] = 4u * (MODE == 2 ? (unsigned)(krow * ld + x) : (unsigned)(x * ld + krow));
+    }
+    kstep = 4u * (unsigned)ld;
+  }
+  __device__ __forceinline__ void init_act(const float *scale, const float *shift, float slope_,
+                                           int64_t x0, int64_t xlim, int64_t k0) {
+    if (!ACT) return;
+    act_scale = scale; act_shift = shift; slope = slope_;
+    if (MODE == 2) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        int64_t x = x0 + row(a);
+        if (x >= xlim) x = xlim - 1;
+        sc[a] = scale[x]; sh[a] = shift[x];
+      }
+    } else {
+      fpos = (unsigned)(k0 + krow);
+    }
+  }
+  // MODE 0/1: scale / shift of the 4 k of tile `tile_index` (relative to the first), of which
+  // `valid` exist; called right before that tile is transformed
+  __device__ __forceinline__ void load_act(int tile_index, int valid) {
+    if (!ACT || MODE == 2) return;
+    const unsigned f = fpos + (unsigned)tile_index * BK;
+    if (valid >= 4) {
+      const float4 a = *reinterpret_cast<const float4 *>(act_scale + f);
+      const float4 b = *reinterpret_cast<const float4 *>(act_shift + f);
+      sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w;
+      sh[0] = b.x; sh[1] = b.y; sh[2] = b.z; sh[3] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = j < valid;
+        sc[j] = ok ? act_scale[f + j] : 0.f;
+        sh[j] = ok ? act_shift[f + j] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void advance() { tile += MODE == 2 ? (int64_t)BK * kstep : 4 * BK; }
+
+  __device__ __forceinline__ static void load16(f32x4 &dst, unsigned o, const char *base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(o), "s"(base));
+  }
+  __device__ __forceinline__ static void load4(float &dst, unsigned o, const char *base) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(o), "s"(base));
+  }
+  // issue the LOADS loads of a full k-tile
+  __device__ __forceinline__ void load(Regs &r) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if constexpr (MODE == 0) {
+        load16(r.q[a], off[a], tile);
+      } else if constexpr (MODE == 1) {
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(r.v[4 * a]) : "v"(off[a]), "s"(tile));
+        asm volatile("global_load_dword %0, %1, %2 offset:4" : "=v"(r.v[4 * a + 1]) : "v"(off[a]), "s"(tile));
+        asm volatile("global_load_dword %0, %1, %2 offset:8" : "=v"(r.v[4 * a + 2]) : "v"(off[a]), "s"(tile));
+        asm volatile("global_load_dword %0, %1, %2 offset:12" : "=v"(r.v[4 * a + 3]) : "v"(off[a]), "s"(tile));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load4(r.v[4 * a + j], off[a] + j * kstep, tile);
+      }
+    }
+  }
+  // the same number of loads for the partial last k-tile: of its `rem` valid k; the others read
+  // k 0 of the thread's row and are zeroed by zero_tail() once they have landed
+  __device__ __forceinline__ void load_tail(Regs &r, int rem) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if constexpr (MODE == 0) {
+        // rem % 4 == 0 here (16-byte loads need K % 4 == 0): the four k are valid together
+        load16(r.q[a], krow < rem ? off[a] : off[a] - 4u * krow, tile);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = krow + j < rem;
+          const unsigned o = MODE == 2 ? (ok ? off[a] + j * kstep : off[a] - krow * kstep)
+                                       : (ok ? off[a] + 4u * j : off[a] - 4u * krow);
+          load4(r.v[4 * a + j], o, tile);
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void zero_tail(Regs &r, int rem) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (krow + j >= rem) r.set(a, j, 0.f);
+  }
+  // the prologue on a landed tile.  Zero-filled k of a partial tile stay zero for f = k
+  // (scale = shift = 0 there); for f = x they become lrelu(shift), harmless because the other
+  // operand's zero-filled k multiply them.
+  __device__ __forceinline__ void transform(Regs &r) const {
+    if (!ACT) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float y = r.get(a, j) * sc[MODE == 2 ? a : j] + sh[MODE == 2 ? a : j];
+        r.set(a, j, fmaxf(y, y * slope));
+      }
+  }
+  // three bf16 planes of the 16 elements into the operand's LDS tile
+  __device__ __forceinline__ void split_store(const Regs &r, char *lds) const {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float x0 = r.get(a, 0), x1 = r.get(a, 1), x2 = r.get(a, 2), x3 = r.get(a, 3);
+      const unsigned p01 = pack_bf16(x0, x1), p23 = pack_bf16(x2, x3);
+      const float e0 = x0 - __uint_as_float(p01 << 16), e1 = x1 - __uint_as_float(p01 & 0xffff0000u);
+      const float e2 = x2 - __uint_as_float(p23 << 16), e3 = x3 - __uint_as_float(p23 & 0xffff0000u);
+      const unsigned q01 = pack_bf16(e0, e1), q23 = pack_bf16(e2, e3);
+      const float f0 = e0 - __uint_as_float(q01 << 16), f1 = e1 - __uint_as_float(q01 & 0xffff0000u);
+      const float f2 = e2 - __uint_as_float(q23 << 16), f3 = e3 - __uint_as_float(q23 & 0xffff0000u);
+      const unsigned s01 = pack_bf16(f0, f1), s23 = pack_bf16(f2, f3);
+      char *dst = lds + plane_offset(row(a), piece());
+      *reinterpret_cast<uint2 *>(dst) = make_uint2(p01, p23);
+      *reinterpret_cast<uint2 *>(dst + PLANE_BYTES) = make_uint2(q01, q23);
+      *reinterpret_cast<uint2 *>(dst + 2 * PLANE_BYTES) = make_uint2(s01, s23);
+    }
+  }
+};
+
+// the three planes of one 32-row sub-tile for one 16-deep k-step
+__device__ __forceinline__ void read_set(const char *lds, int row0, int lane, int step, bf16x8 (&f)[3]) {
+  const int rowi = row0 + (lane & 31);
+  const char *p = lds + plane_offset(rowi, 2 * (2 * step + (lane >> 5)));
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) f[pl] = *reinterpret_cast<const bf16x8 *>(p + pl * PLANE_BYTES);
+}
+
+// the six partial products of one 32x32 tile for one k-step: a0 b0 -> hi, the corrections -> lo
+// (six back-to-back matrix instructions, nothing for the vector ALU to do)
+__device__ __forceinline__ void mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 &hi, f32x16 &lo) {
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
+}
+
+// 512 threads = four consumer waves (0-3) and four producer waves (4-7): see the head of the file.
+// Measured per k-tile at 51200 x 1000 x 1000 (in-kernel cycle stamps): consumers 1875 cycles
+// between barriers (1536 = 48 matrix instructions of 32 cycles), producers 2050-2230 for about 210
+// vector instructions, 12 LDS stores and 8 loads beside them - the vector side is the longer
+// pole of a tile.  (Earlier forms - waves that alternate split and multiply phases, alone or as
+// two workgroups in anti-phase - left the matrix pipe 44 % busy: the two phases did not overlap.)
+template <int A_MODE, int B_MODE, int ACT>
+__global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
+  static_assert(ACT == 0 || (ACT == 1 && A_MODE != 2) || (ACT == 2 && B_MODE == 2), "prologue orientation");
+  extern __shared__ __align__(16) char smem[];               // [buffer][A planes | B planes]
+  const bool producer = threadIdx.x >= 256;
+  const int t = threadIdx.x & 255;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // workgroup id -> (output tile, k-split): as gemm_f32_kernel
+  const int tail_units = g.tail_splits > 1;
+  const int nwg = tail_units ? (int)g.tail_first : (int)gridDim.x;
+  const int bid = blockIdx.x;
+  int tile, sp;
+  int64_t kchunk;
+  const bool tail = tail_units && bid >= nwg;
+  if (tail) {
+    const int u = bid - nwg;
+    tile = nwg + u / (int)g.tail_splits;
+    sp = u % (int)g.tail_splits;
+    kchunk = g.tail_kchunk;
+  } else {
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int tiles = (int)(g.tiles_n * g.tiles_m);
+    tile = L % tiles;
+    sp = L / tiles;
+    kchunk = g.k_chunk;
+  }
+  tile = __builtin_amdgcn_readfirstlane(tile);
+  sp = __builtin_amdgcn_readfirstlane(sp);
+  const int tn = __builtin_amdgcn_readfirstlane(tile % (int)g.tiles_n);
+  const int tm = __builtin_amdgcn_readfirstlane(tile / (int)g.tiles_n);
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  const int64_t kbeg = sp * kchunk;
+  const int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
+  const int64_t klen = kend > kbeg ? kend - kbeg : 0;
+  const int ntf = __builtin_amdgcn_readfirstlane((int)(klen / BK));          // full k-tiles
+  const int rem = __builtin_amdgcn_readfirstlane((int)(klen - (int64_t)ntf * BK));
+  const int nt = ntf + (rem ? 1 : 0);
+
+  if (producer) {
+    Split<A_MODE, ACT == 1> sa;
+    Split<B_MODE, ACT == 2> sb;
+    sa.init(g.A, g.lda, m0, g.M, kbeg, t);
+    sb.init(g.B, g.ldb, n0, g.N, kbeg, t);
+    sa.init_act(g.act_scale, g.act_shift, g.act_slope, m0, g.M, kbeg);
+    sb.init_act(g.act_scale, g.act_shift, g.act_slope, n0, g.N, kbeg);
+    typename Split<A_MODE, ACT == 1>::Regs ra0, ra1;
+    typename Split<B_MODE, ACT == 2>::Regs rb0, rb1;
+    constexpr int TILE_LOADS = Split<A_MODE, ACT == 1>::LOADS + Split<B_MODE, ACT == 2>::LOADS;
+    // tile `it` lives in set it&1; the loads of tile it+2 are issued as soon as tile it is split,
+    // so when tile it is needed only the TILE_LOADS loads of tile it+1 are younger than its own
+#define TV_LOAD(IT, RA, RB)                                                       \
+  do {                                                                            \
+    if ((IT) < ntf) { sa.load(RA); sb.load(RB); }                                 \
+    else if ((IT) < nt) { sa.load_tail(RA, rem); sb.load_tail(RB, rem); }         \
+    if ((IT) < nt) { sa.advance(); sb.advance(); }                                \
+  } while (0)
+#define TV_STAGE(IT, RA, RB)                                                      \
+  do {                                                                            \
+    if ((IT) < nt) {                                                              \
+      char *buf = smem + ((IT) & 1) * (2 * OPERAND_BYTES);                        \
+      sa.load_act((IT), (IT) < ntf ? 4 : rem - sa.krow);                          \
+      sb.load_act((IT), (IT) < ntf ? 4 : rem - sb.krow);                          \
+      if ((IT) + 1 < nt) wait_loads_but<TILE_LOADS>(); else wait_loads_but<0>();  \
+      RA.landed(); RB.landed();                                                   \
+      if ((IT) >= ntf) { sa.zero_tail(RA, rem); sb.zero_tail(RB, rem); }          \
+      sa.transform(RA); sb.transform(RB);                                         \
+      sa.split_store(RA, buf);                                                    \
+      sb.split_store(RB, buf + OPERAND_BYTES);                                    \
+      TV_LOAD((IT) + 2, RA, RB);                                                  \
+    }                                                                             \
+    __syncthreads();                                                              \
+  } while (0)
+    TV_LOAD(0, ra0, rb0);
+    TV_LOAD(1, ra1, rb1);
+    // nt + 1 barriers, like the consumers
+    for (int it = 0; it <= nt; it += 2) {
+      TV_STAGE(it, ra0, rb0);
+      if (it + 1 <= nt) TV_STAGE(it + 1, ra1, rb1);
+    }
+#undef TV_STAGE
+#undef TV_LOAD
+    return;
+  }
+
+  f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+
+  __syncthreads();                                 // tile 0 is in buffer 0
+  for (int it = 0; it < nt; ++it) {
+    const char *As = smem + (it & 1) * (2 * OPERAND_BYTES), *Bs = As + OPERAND_BYTES;
+    // Both 16-deep k-steps (a partial tile's missing k were stored as zeros).  Four fragment
+    // sets (A0, B0, B1, A1 of a step; 3 planes = 12 registers each) are refilled as soon as
+    // their last use has been issued, one or two stages (6-12 MFMAs, 200-400 cycles) ahead of
+    // their next use; the stage order is pinned, so the matrix pipe only waits for LDS at the
+    // head of a tile.
+    //   stage : 1      2      3      4    | 5       6      7      8
+    //   tile  : (0,0)  (0,1)  (1,1)  (1,0)| (0,1)   (0,0)  (1,0)  (1,1)
+    //   sets  : P Q    P R    S R    S Q  | P R     P Q    S Q    S R
+    //   refill: -      -      P=A0'  R=B1'| Q=B0',S=A1'
+    bf16x8 P[3], Q[3], R[3], S[3];
+    read_set(As, wm * 64, lane, 0, P);           // A0 step 0
+    read_set(Bs, wn * 64, lane, 0, Q);           // B0 step 0
+    read_set(Bs, wn * 64 + 32, lane, 0, R);      // B1 step 0
+    read_set(As, wm * 64 + 32, lane, 0, S);      // A1 step 0
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(P, Q, hi[0][0], lo[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(P, R, hi[0][1], lo[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(As, wm * 64, lane, 1, P);           // A0 step 1
+    mma6(S, R, hi[1][1], lo[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(Bs, wn * 64 + 32, lane, 1, R);      // B1 step 1
+    mma6(S, Q, hi[1][0], lo[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(Bs, wn * 64, lane, 1, Q);           // B0 step 1
+    read_set(As, wm * 64 + 32, lane, 1, S);      // A1 step 1
+    mma6(P, R, hi[0][1], lo[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(P, Q, hi[0][0], lo[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(S, Q, hi[1][0], lo[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(S, R, hi[1][1], lo[1][1]);
+    __syncthreads();                               // buffer it&1 may be refilled, (it+1)&1 is ready
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hi[i][j][r] += lo[i][j][r];
+
+  // the producers are gone and every consumer is past the last barrier: the LDS is free
+  gemm_epilogue(g, hi, reinterpret_cast<float *>(smem), tile, sp, tail, nwg, m0, n0, wave, lane);
 }
 
 // second stage of split-K: out = epilogue(sum_s slab[s]) in slab order
@@ -634,7 +685,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   TV_REQUIRE(ldb >= (trans_b ? k : n), "tv_gemm_f32: ldb %lld too small", (long long)ldb);
   TV_REQUIRE(ldc >= n, "tv_gemm_f32: ldc %lld too small", (long long)ldc);
   TV_REQUIRE(k > 0, "tv_gemm_f32: k must be positive");
-  TV_REQUIRE(lda < (1ll << 24) && ldb < (1ll << 24), "tv_gemm_f32: leading dimension too large");
+  TV_REQUIRE(lda < (1ll << 22) && ldb < (1ll << 22), "tv_gemm_f32: leading dimension too large");
 
   GemmArgs g;
   g.A = a; g.B = b; g.C = c; g.bias = bias; g.row_scale = row_scale;
@@ -678,40 +729,36 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   const int64_t nwg = g.tail_splits > 1 ? g.tail_first + (tiles - g.tail_first) * g.tail_splits
                                         : tiles * g.splits;
   TV_REQUIRE(nwg < (1ll << 31), "tv_gemm_f32: grid too large");
-  const dim3 grid((unsigned)nwg), block(256);
-  const int variant = (trans_a != 0 ? 8 : 0) | (trans_b == 0 ? 4 : 0) | (g.a_vec ? 2 : 0) |
-                      (g.b_vec ? 1 : 0);
-#define TV_GEMM_ACT_CASE(V, AK, BK_, AV, BV, ACT)                                               \
-  case V: hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, AV, BV, ACT>), grid, block, 0, s, g); break;
-  if (act_operand == 1) {          // A row-major
-    switch (variant) {
-      TV_GEMM_ACT_CASE(0, false, false, false, false, 1) TV_GEMM_ACT_CASE(1, false, false, false, true, 1)
-      TV_GEMM_ACT_CASE(2, false, false, true, false, 1)  TV_GEMM_ACT_CASE(3, false, false, true, true, 1)
-      TV_GEMM_ACT_CASE(4, false, true, false, false, 1)  TV_GEMM_ACT_CASE(5, false, true, false, true, 1)
-      TV_GEMM_ACT_CASE(6, false, true, true, false, 1)   TV_GEMM_ACT_CASE(7, false, true, true, true, 1)
-    }
-  } else if (act_operand == 2) {   // B k-major
-    switch (variant) {
-      TV_GEMM_ACT_CASE(4, false, true, false, false, 2)  TV_GEMM_ACT_CASE(5, false, true, false, true, 2)
-      TV_GEMM_ACT_CASE(6, false, true, true, false, 2)   TV_GEMM_ACT_CASE(7, false, true, true, true, 2)
-      TV_GEMM_ACT_CASE(12, true, true, false, false, 2)  TV_GEMM_ACT_CASE(13, true, true, false, true, 2)
-      TV_GEMM_ACT_CASE(14, true, true, true, false, 2)   TV_GEMM_ACT_CASE(15, true, true, true, true, 2)
-    }
-  } else
-#define TV_GEMM_CASE(V, AK, BK_, AV, BV)                                                        \
-  case V: hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, AV, BV>), grid, block, 0, s, g); break;
-  switch (variant) {
-    TV_GEMM_CASE(0, false, false, false, false) TV_GEMM_CASE(1, false, false, false, true)
-    TV_GEMM_CASE(2, false, false, true, false)  TV_GEMM_CASE(3, false, false, true, true)
-    TV_GEMM_CASE(4, false, true, false, false)  TV_GEMM_CASE(5, false, true, false, true)
-    TV_GEMM_CASE(6, false, true, true, false)   TV_GEMM_CASE(7, false, true, true, true)
-    TV_GEMM_CASE(8, true, false, false, false)  TV_GEMM_CASE(9, true, false, false, true)
-    TV_GEMM_CASE(10, true, false, true, false)  TV_GEMM_CASE(11, true, false, true, true)
-    TV_GEMM_CASE(12, true, true, false, false)  TV_GEMM_CASE(13, true, true, false, true)
-    TV_GEMM_CASE(14, true, true, true, false)   TV_GEMM_CASE(15, true, true, true, true)
+  const dim3 grid((unsigned)nwg), block(512);
+  const size_t lds = 4 * (size_t)OPERAND_BYTES;             // two buffers x (A planes | B planes)
+  int device = 0;
+  TV_HIP(hipGetDevice(&device));
+  // load mode of each operand: 0 = [x][k] 16-byte loads, 1 = [x][k] 4-byte loads, 2 = [k][x]
+  const int am = trans_a ? 2 : (g.a_vec ? 0 : 1);
+  const int bm = trans_b ? (g.b_vec ? 0 : 1) : 2;
+#define TV_GEMM(AM, BM_, ACT)                                                                    \
+  do {                                                                                           \
+    static bool raised[64] = {};  /* 96 KB of dynamic LDS: once per kernel and device */       \
+    if (!raised[device & 63]) {                                                                  \
+      TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<AM, BM_, ACT>),     \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+      raised[device & 63] = true;                                                                \
+    }                                                                                            \
+    hipLaunchKernelGGL((gemm_kernel<AM, BM_, ACT>), grid, block, lds, s, g);                     \
+  } while (0)
+#define TV_GEMM_B(AM, ACT)                                                                       \
+  do {                                                                                           \
+    if (bm == 0) TV_GEMM(AM, 0, ACT); else if (bm == 1) TV_GEMM(AM, 1, ACT); else TV_GEMM(AM, 2, ACT); \
+  } while (0)
+  if (act_operand == 1) {            // A row-major
+    if (am == 0) TV_GEMM_B(0, 1); else TV_GEMM_B(1, 1);
+  } else if (act_operand == 2) {     // B k-major
+    if (am == 0) TV_GEMM(0, 2, 2); else if (am == 1) TV_GEMM(1, 2, 2); else TV_GEMM(2, 2, 2);
+  } else {
+    if (am == 0) TV_GEMM_B(0, 0); else if (am == 1) TV_GEMM_B(1, 0); else TV_GEMM_B(2, 0);
   }
-#undef TV_GEMM_CASE
-#undef TV_GEMM_ACT_CASE
+#undef TV_GEMM_B
+#undef TV_GEMM
   TV_LAUNCH_CHECK("tv_gemm_f32");
   if (g.splits > 1) {
     int64_t blocks = tv_cdiv(m * n, 256);
