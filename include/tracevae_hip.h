@@ -151,9 +151,11 @@ int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int64_t num_ed
  * backward (dX = dY.W, dW = dY^T.X use the same kernel with other trans flags; a
  * reduction over many rows is split over K with a fixed-order second-stage sum).
  * bias / row_scale may be NULL.  accumulate != 0 adds into C.
- * Workspace: tv_gemm_f32_workspace_bytes(m, n, k) bytes of device memory (0 for many shapes),
- * used for the split-K slabs of weight-gradient shapes and for the K-split of the output tiles
- * of a partial last round of workgroups (both summed in a fixed order by a second kernel).
+ * Workspace: tv_gemm_f32_workspace_bytes(m, n, k) bytes of 16-byte aligned device memory (0 for
+ * many shapes), used for the split-K slabs of weight-gradient shapes, for the K-split of the
+ * output tiles of a partial last round of workgroups (both summed in a fixed order by a second
+ * kernel), and for the bf16 pieces of a small B that is split once per call (m >= 2048,
+ * n * k <= 2^22: 6 bytes per padded element).
  * ---------------------------------------------------------------------------------- */
 int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,

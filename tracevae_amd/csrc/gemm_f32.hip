@@ -30,6 +30,11 @@
 // thread owns 4 rows x 4 consecutive k of each operand:
 //   [x][k] storage: row (t>>3) + 32a, k = 4(t&7) .. +3   (one 16-byte load, or four 4-byte loads)
 //   [k][x] storage: row (t&31) + 32a, k = 4(t>>5) .. +3  (four 4-byte loads, 128 B per half-wave)
+// A small B under many rows (a layer's weights: n*k <= 4M elements, m >= 2048) is split ONCE per
+// call by gemm_split_b_kernel into the LDS images of its tiles (24 KB each, in the workspace);
+// the producers then copy 96 bytes per thread and tile instead of splitting it again for each
+// of the m/128 row tiles, and a k-major weight matrix (the input-gradient product) needs no
+// 4-byte loads.
 // Edges: out-of-range rows/columns read a clamped (valid) address and only ever reach
 // accumulators that are not stored; the one partial k-tile is loaded through a masked path.
 // Workgroup ids are remapped so that the workgroups sharing an XCD (ids equal mod 8) walk a
@@ -41,6 +46,7 @@
 // is split over K into slabs and summed by a second kernel in slab order (deterministic).
 #include "tv_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -68,6 +74,9 @@ struct GemmArgs {
   // into LDS, f = the operand's feature index (k for a row-major A, n for a k-major B)
   const float *act_scale, *act_shift;
   float act_slope;
+  // B already split (gemm_split_b_kernel): LDS images of its tiles, [n-tile][k-tile][24 KB]
+  const char *b_planes;
+  int64_t b_ktiles;
 };
 
 // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -221,14 +230,30 @@ struct TileRegs<0> {                             // 16-byte loads: one register 
   }
 };
 
+// ... plus, for an operand with a prologue along k, the scale and shift of the thread's four k
+template <int MODE, bool COEF>
+struct SetRegs : TileRegs<MODE> {};
+template <int MODE>
+struct SetRegs<MODE, true> : TileRegs<MODE> {
+  f32x4 cs, ch;
+  __device__ __forceinline__ void landed() {
+    TileRegs<MODE>::landed();
+    asm volatile("" : "+v"(cs), "+v"(ch));
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_loads_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
 
 // MODE 0: [x][k] storage, 16-byte loads; 1: [x][k], 4-byte loads; 2: [k][x], 4-byte loads.
 template <int MODE, bool ACT>
 struct Split {
-  static constexpr int LOADS = MODE == 0 ? 4 : 16;     // load instructions per tile and thread
-  using Regs = TileRegs<MODE == 0 ? 0 : 1>;
+  // The coefficients of a prologue along k (MODE 0/1) travel with the tile, in the same register
+  // set and by the same kind of load: a load the compiler counts would make it wait for every
+  // load in flight, the two tiles of prefetch included.
+  static constexpr bool COEF = ACT && MODE != 2;
+  static constexpr int LOADS = (MODE == 0 ? 4 : 16) + (COEF ? 2 : 0);   // loads per tile and thread
+  using Regs = SetRegs<MODE == 0 ? 0 : 1, COEF>;
   const char *tile;             // origin of the current k-tile (wave-uniform: stays in SGPRs)
   unsigned off[4];              // BYTE offset of row a's first k (MODE 2: of column a at the
                                 // thread's first k) from `tile`
@@ -237,8 +262,9 @@ struct Split {
   // prologue: lrelu(v * scale[f] + shift[f]); f = k for MODE 0/1 (A), f = x for MODE 2 (B)
   const float *act_scale, *act_shift;
   float slope;
-  float sc[4], sh[4];           // MODE 2: fixed per thread; MODE 0/1: of the tile being split
-  unsigned fpos;                // MODE 0/1: first k of the first tile
+  float sc[4], sh[4];           // MODE 2: fixed per thread
+  unsigned kpos;                // MODE 0/1: the thread's first k in the tile the next load() fetches
+  unsigned kfirst;              //           ... and in the first tile
 
   __device__ __forceinline__ int row(int a) const { return MODE == 2 ? (t & 31) + 32 * a : (t >> 3) + 32 * a; }
   __device__ __forceinline__ int piece() const { return MODE == 2 ? (t >> 5) : (t & 7); }
@@ -268,29 +294,13 @@ struct Split {
         sc[a] = scale[x]; sh[a] = shift[x];
       }
     } else {
-      fpos = (unsigned)(k0 + krow);
+      kpos = kfirst = (unsigned)(k0 + krow);
     }
   }
-  // MODE 0/1: scale / shift of the 4 k of tile `tile_index` (relative to the first), of which
-  // `valid` exist; called right before that tile is transformed
-  __device__ __forceinline__ void load_act(int tile_index, int valid) {
-    if (!ACT || MODE == 2) return;
-    const unsigned f = fpos + (unsigned)tile_index * BK;
-    if (valid >= 4) {
-      const float4 a = *reinterpret_cast<const float4 *>(act_scale + f);
-      const float4 b = *reinterpret_cast<const float4 *>(act_shift + f);
-      sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w;
-      sh[0] = b.x; sh[1] = b.y; sh[2] = b.z; sh[3] = b.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = j < valid;
-        sc[j] = ok ? act_scale[f + j] : 0.f;
-        sh[j] = ok ? act_shift[f + j] : 0.f;
-      }
-    }
+  __device__ __forceinline__ void advance() {
+    tile += MODE == 2 ? (int64_t)BK * kstep : 4 * BK;
+    if (COEF) kpos += BK;
   }
-  __device__ __forceinline__ void advance() { tile += MODE == 2 ? (int64_t)BK * kstep : 4 * BK; }
 
   __device__ __forceinline__ static void load16(f32x4 &dst, unsigned o, const char *base) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(o), "s"(base));
@@ -314,6 +324,10 @@ struct Split {
         for (int j = 0; j < 4; ++j) load4(r.v[4 * a + j], off[a] + j * kstep, tile);
       }
     }
+    if constexpr (COEF) {
+      load16(r.cs, 4u * kpos, reinterpret_cast<const char *>(act_scale));
+      load16(r.ch, 4u * kpos, reinterpret_cast<const char *>(act_shift));
+    }
   }
   // the same number of loads for the partial last k-tile: of its `rem` valid k; the others read
   // k 0 of the thread's row and are zeroed by zero_tail() once they have landed
@@ -333,13 +347,31 @@ struct Split {
         }
       }
     }
+    if constexpr (COEF) {
+      // the thread's four coefficients when they all exist, else the first four of the vectors
+      // (K >= 4, checked on the host); zero_tail() puts the right values there
+      const bool whole = krow + 4 <= rem;
+      load16(r.cs, whole ? 4u * kpos : 0u, reinterpret_cast<const char *>(act_scale));
+      load16(r.ch, whole ? 4u * kpos : 0u, reinterpret_cast<const char *>(act_shift));
+    }
   }
-  __device__ __forceinline__ void zero_tail(Regs &r, int rem) const {
+  // `it` = index of the (partial) tile among the tiles of this workgroup
+  __device__ __forceinline__ void zero_tail(Regs &r, int rem, int it) const {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (krow + j >= rem) r.set(a, j, 0.f);
+    if constexpr (COEF) {
+      if (krow + 4 > rem) {                      // coefficients of k that do not exist are zero
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = krow + j < rem;
+          r.cs[j] = ok ? act_scale[kfirst + (unsigned)it * BK + j] : 0.f;
+          r.ch[j] = ok ? act_shift[kfirst + (unsigned)it * BK + j] : 0.f;
+        }
+      }
+    }
   }
   // the prologue on a landed tile.  Zero-filled k of a partial tile stay zero for f = k
   // (scale = shift = 0 there); for f = x they become lrelu(shift), harmless because the other
@@ -350,7 +382,9 @@ struct Split {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float y = r.get(a, j) * sc[MODE == 2 ? a : j] + sh[MODE == 2 ? a : j];
+        float y;
+        if constexpr (COEF) y = r.get(a, j) * r.cs[j] + r.ch[j];
+        else y = r.get(a, j) * sc[a] + sh[a];
         r.set(a, j, fmaxf(y, y * slope));
       }
   }
@@ -373,6 +407,76 @@ struct Split {
     }
   }
 };
+
+// An operand that gemm_split_b_kernel has already split: its tiles lie in memory as the LDS
+// image (three planes, swizzled), 24 KB each, and a producer thread copies 6 x 16 bytes of it.
+// Same interface as Split, so the producer loop does not care which it has.
+struct PlaneTile {
+  static constexpr int LOADS = 6;
+  struct Regs {
+    f32x4 q[6];
+    __device__ __forceinline__ void landed() {
+      asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]));
+    }
+  };
+  const char *tile;
+  unsigned off;                 // 16 t: the thread's first 16 bytes of the image
+  int krow;
+  __device__ __forceinline__ void init(const char *planes, int64_t ktiles, int64_t tile_n, int64_t k0, int t) {
+    tile = planes + (tile_n * ktiles + k0 / BK) * OPERAND_BYTES;
+    off = 16u * (unsigned)t;
+    krow = 0;
+  }
+  __device__ __forceinline__ void init_act(const float *, const float *, float, int64_t, int64_t, int64_t) {}
+  __device__ __forceinline__ void advance() { tile += OPERAND_BYTES; }
+  __device__ __forceinline__ void load(Regs &r) const {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.q[j]) : "v"(off + 4096u * j), "s"(tile));
+  }
+  __device__ __forceinline__ void load_tail(Regs &r, int) const { load(r); }   // images are zero-padded in k
+  __device__ __forceinline__ void zero_tail(Regs &, int, int) const {}
+  __device__ __forceinline__ void transform(Regs &) const {}
+  __device__ __forceinline__ void split_store(const Regs &r, char *lds) const {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4 *>(lds + off + 4096u * j) = r.q[j];
+  }
+};
+
+// B (the small operand of a layer product: the weight matrix) split once per call instead of
+// once per output tile: one workgroup writes the 24 KB LDS image of one (n-tile, k-tile) pair,
+// zero outside the matrix.  kx: B is stored [k][n] (trans_b = 0), else [n][k].
+__global__ __launch_bounds__(256) void gemm_split_b_kernel(const float *B, int64_t ldb, int kx,
+                                                           int64_t N, int64_t K, int64_t ktiles,
+                                                           char *planes) {
+  const int t = threadIdx.x;
+  const int64_t tn = blockIdx.x / ktiles, kt = blockIdx.x % ktiles;
+  char *image = planes + (int64_t)blockIdx.x * OPERAND_BYTES;
+  // thread -> (4 rows, 4 consecutive k) as the in-kernel split, following the storage order
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = kx ? (t & 31) + 32 * a : (t >> 3) + 32 * a;
+    const int piece = kx ? (t >> 5) : (t & 7);
+    const int64_t n = tn * BN + row, k0 = kt * BK + 4 * piece;
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t k = k0 + j;
+      x[j] = (n < N && k < K) ? (kx ? B[k * ldb + n] : B[n * ldb + k]) : 0.f;
+    }
+    const unsigned p01 = pack_bf16(x[0], x[1]), p23 = pack_bf16(x[2], x[3]);
+    const float e0 = x[0] - __uint_as_float(p01 << 16), e1 = x[1] - __uint_as_float(p01 & 0xffff0000u);
+    const float e2 = x[2] - __uint_as_float(p23 << 16), e3 = x[3] - __uint_as_float(p23 & 0xffff0000u);
+    const unsigned q01 = pack_bf16(e0, e1), q23 = pack_bf16(e2, e3);
+    const float f0 = e0 - __uint_as_float(q01 << 16), f1 = e1 - __uint_as_float(q01 & 0xffff0000u);
+    const float f2 = e2 - __uint_as_float(q23 << 16), f3 = e3 - __uint_as_float(q23 & 0xffff0000u);
+    const unsigned s01 = pack_bf16(f0, f1), s23 = pack_bf16(f2, f3);
+    char *dst = image + plane_offset(row, piece);
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(p01, p23);
+    *reinterpret_cast<uint2 *>(dst + PLANE_BYTES) = make_uint2(q01, q23);
+    *reinterpret_cast<uint2 *>(dst + 2 * PLANE_BYTES) = make_uint2(s01, s23);
+  }
+}
 
 // the three planes of one 32-row sub-tile for one 16-deep k-step
 __device__ __forceinline__ void read_set(const char *lds, int row0, int lane, int step, bf16x8 (&f)[3]) {
@@ -402,6 +506,7 @@ __device__ __forceinline__ void mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3],
 template <int A_MODE, int B_MODE, int ACT>
 __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
   static_assert(ACT == 0 || (ACT == 1 && A_MODE != 2) || (ACT == 2 && B_MODE == 2), "prologue orientation");
+  static_assert(B_MODE >= 0 && B_MODE <= 3 && A_MODE >= 0 && A_MODE <= 2, "load modes");
   extern __shared__ __align__(16) char smem[];               // [buffer][A planes | B planes]
   const bool producer = threadIdx.x >= 256;
   const int t = threadIdx.x & 255;
@@ -443,15 +548,18 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
   const int nt = ntf + (rem ? 1 : 0);
 
   if (producer) {
-    Split<A_MODE, ACT == 1> sa;
-    Split<B_MODE, ACT == 2> sb;
+    using OperandA = Split<A_MODE, ACT == 1>;
+    using OperandB = typename std::conditional<B_MODE == 3, PlaneTile, Split<B_MODE == 3 ? 0 : B_MODE, ACT == 2>>::type;
+    OperandA sa;
+    OperandB sb;
     sa.init(g.A, g.lda, m0, g.M, kbeg, t);
-    sb.init(g.B, g.ldb, n0, g.N, kbeg, t);
+    if constexpr (B_MODE == 3) sb.init(g.b_planes, g.b_ktiles, tn, kbeg, t);
+    else sb.init(g.B, g.ldb, n0, g.N, kbeg, t);
     sa.init_act(g.act_scale, g.act_shift, g.act_slope, m0, g.M, kbeg);
     sb.init_act(g.act_scale, g.act_shift, g.act_slope, n0, g.N, kbeg);
-    typename Split<A_MODE, ACT == 1>::Regs ra0, ra1;
-    typename Split<B_MODE, ACT == 2>::Regs rb0, rb1;
-    constexpr int TILE_LOADS = Split<A_MODE, ACT == 1>::LOADS + Split<B_MODE, ACT == 2>::LOADS;
+    typename OperandA::Regs ra0, ra1;
+    typename OperandB::Regs rb0, rb1;
+    constexpr int TILE_LOADS = OperandA::LOADS + OperandB::LOADS;
     // tile `it` lives in set it&1; the loads of tile it+2 are issued as soon as tile it is split,
     // so when tile it is needed only the TILE_LOADS loads of tile it+1 are younger than its own
 #define TV_LOAD(IT, RA, RB)                                                       \
@@ -464,11 +572,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
   do {                                                                            \
     if ((IT) < nt) {                                                              \
       char *buf = smem + ((IT) & 1) * (2 * OPERAND_BYTES);                        \
-      sa.load_act((IT), (IT) < ntf ? 4 : rem - sa.krow);                          \
-      sb.load_act((IT), (IT) < ntf ? 4 : rem - sb.krow);                          \
       if ((IT) + 1 < nt) wait_loads_but<TILE_LOADS>(); else wait_loads_but<0>();  \
       RA.landed(); RB.landed();                                                   \
-      if ((IT) >= ntf) { sa.zero_tail(RA, rem); sb.zero_tail(RB, rem); }          \
+      if ((IT) >= ntf) { sa.zero_tail(RA, rem, (IT)); sb.zero_tail(RB, rem, (IT)); } \
       sa.transform(RA); sb.transform(RB);                                         \
       sa.split_store(RA, buf);                                                    \
       sb.split_store(RB, buf + OPERAND_BYTES);                                    \
@@ -597,7 +703,7 @@ __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(GemmArgs g) {
   }
 }
 
-// workgroups resident at once: two per CU (LDS-bound)
+// workgroups resident at once: one per CU (96 KB of LDS each)
 int64_t resident_workgroups() {
   static int64_t slots = 0;
   if (slots == 0) {
@@ -605,7 +711,7 @@ int64_t resident_workgroups() {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
-    slots = 2 * (int64_t)cus;
+    slots = (int64_t)cus;
   }
   return slots;
 }
@@ -613,6 +719,8 @@ int64_t resident_workgroups() {
 struct Plan {
   int64_t splits, k_chunk;                          // whole-problem split-K
   int64_t tail_first, tail_splits, tail_kchunk;     // tail split (mutually exclusive with it)
+  int64_t slab_bytes;                               // slabs of either split, at the workspace's start
+  int64_t planes_bytes;                             // pre-split B behind them (0: split in the kernel)
   int64_t workspace_bytes;
 };
 
@@ -625,7 +733,7 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
   p.k_chunk = tv_cdiv(tv_cdiv(k, p.splits), BK) * BK;
   p.splits = tv_cdiv(k, p.k_chunk);
   p.tail_first = tiles; p.tail_splits = 1; p.tail_kchunk = p.k_chunk;
-  p.workspace_bytes = p.splits > 1 ? p.splits * m * n * (int64_t)sizeof(float) : 0;
+  p.slab_bytes = p.splits > 1 ? p.splits * m * n * (int64_t)sizeof(float) : 0;
   const int64_t slots = resident_workgroups();
   static const bool tail_enabled = [] { const char *e = getenv("TV_GEMM_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
   if (tail_enabled && p.splits == 1 && tiles > slots && tiles < (1ll << 30)) {
@@ -640,11 +748,18 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
         ts = tv_cdiv(k, kc);
         if (ts >= 2) {
           p.tail_first = tiles - tail; p.tail_splits = ts; p.tail_kchunk = kc;
-          p.workspace_bytes = tail * ts * (int64_t)(BM * BN * sizeof(float));
+          p.slab_bytes = tail * ts * (int64_t)(BM * BN * sizeof(float));
         }
       }
     }
   }
+  // B is split ahead of the product when it is small and every piece of it is needed by many
+  // row tiles (a layer's weights under >= 2048 rows): 6 bytes per element of scratch
+  p.planes_bytes = 0;
+  if (m >= 2048 && n * k <= (1ll << 22))
+    p.planes_bytes = tv_cdiv(n, BN) * tv_cdiv(k, BK) * (int64_t)OPERAND_BYTES;
+  p.slab_bytes = (p.slab_bytes + 255) & ~255ll;
+  p.workspace_bytes = p.slab_bytes + p.planes_bytes;
   return p;
 }
 
@@ -705,6 +820,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     TV_REQUIRE((((uintptr_t)act_scale | (uintptr_t)act_shift) & 15) == 0,
                "tv_gemm_f32_act: scale / shift must be 16-byte aligned");
     TV_REQUIRE(act_slope >= 0.f && act_slope <= 1.f, "tv_gemm_f32_act: slope must be in [0, 1]");
+    TV_REQUIRE(act_operand != 1 || k >= 4, "tv_gemm_f32_act: the A prologue needs k >= 4");
   }
   // 16-B loads need aligned rows and a contiguous extent that is a multiple of 4
   g.a_vec = (lda % 4 == 0) && (((uintptr_t)a & 15) == 0) && ((trans_a ? m : k) % 4 == 0);
@@ -720,11 +836,23 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     if (g.splits > 1) {
       g.slabs = (float *)workspace;      // the kernel's output is then a slab: [M, N] rows
       g.c_vec = (n % 4 == 0) && (((uintptr_t)workspace & 15) == 0);
-    } else {
+    } else if (g.tail_splits > 1) {
       g.tail_slabs = (float *)workspace;
     }
   }
   hipStream_t s = (hipStream_t)stream;
+  // the small operand split once, ahead of the product (not with a prologue on B: that is the
+  // weight-gradient form, whose B is the activation matrix)
+  const bool presplit = plan.planes_bytes > 0 && act_operand != 2;
+  g.b_planes = nullptr; g.b_ktiles = tv_cdiv(k, BK);
+  if (presplit) {
+    TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gemm_f32: workspace must be 16-byte aligned");
+    char *planes = (char *)workspace + plan.slab_bytes;
+    g.b_planes = planes;
+    hipLaunchKernelGGL(gemm_split_b_kernel, dim3((unsigned)(g.tiles_n * g.b_ktiles)), dim3(256), 0, s,
+                       b, ldb, trans_b ? 0 : 1, n, k, g.b_ktiles, planes);
+    TV_LAUNCH_CHECK("tv_gemm_f32(split of B)");
+  }
   const int64_t tiles = g.tiles_m * g.tiles_n;
   const int64_t nwg = g.tail_splits > 1 ? g.tail_first + (tiles - g.tail_first) * g.tail_splits
                                         : tiles * g.splits;
@@ -735,7 +863,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   TV_HIP(hipGetDevice(&device));
   // load mode of each operand: 0 = [x][k] 16-byte loads, 1 = [x][k] 4-byte loads, 2 = [k][x]
   const int am = trans_a ? 2 : (g.a_vec ? 0 : 1);
-  const int bm = trans_b ? (g.b_vec ? 0 : 1) : 2;
+  const int bm = presplit ? 3 : trans_b ? (g.b_vec ? 0 : 1) : 2;
 #define TV_GEMM(AM, BM_, ACT)                                                                    \
   do {                                                                                           \
     static bool raised[64] = {};  /* 96 KB of dynamic LDS: once per kernel and device */       \
@@ -748,7 +876,8 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   } while (0)
 #define TV_GEMM_B(AM, ACT)                                                                       \
   do {                                                                                           \
-    if (bm == 0) TV_GEMM(AM, 0, ACT); else if (bm == 1) TV_GEMM(AM, 1, ACT); else TV_GEMM(AM, 2, ACT); \
+    if (bm == 0) TV_GEMM(AM, 0, ACT); else if (bm == 1) TV_GEMM(AM, 1, ACT);                     \
+    else if (bm == 2) TV_GEMM(AM, 2, ACT); else TV_GEMM(AM, 3, ACT);                             \
   } while (0)
   if (act_operand == 1) {            // A row-major
     if (am == 0) TV_GEMM_B(0, 1); else TV_GEMM_B(1, 1);
