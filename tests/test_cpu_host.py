@@ -27,10 +27,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.tv_version() == 1
     assert hip.query('tv_stat_blocks', 1) == 1 and hip.query('tv_stat_blocks', 10 ** 9) == 512
-    # one resident round of tiles needs no workspace; a partial last round is split over K
-    assert hip.query('tv_gemm_f32_workspace_bytes', 4096, 1024, 1000) == 0
-    assert hip.query('tv_gemm_f32_workspace_bytes', 51200, 1000, 1000) % (128 * 128 * 4) == 0
-    assert hip.query('tv_gemm_f32_workspace_bytes', 1000, 1000, 51200) > 0
+    # a small product needs no workspace; a small B under >= 2048 rows is split once per call
+    # into the LDS images of its tiles (24 KB per 128 x 32 tile); a partial last round of
+    # workgroups is split over K into 128 x 128 slabs in front of them; a weight-gradient shape
+    # gets split-K slabs
+    image = 3 * 128 * 64
+    assert hip.query('tv_gemm_f32_workspace_bytes', 100, 100, 100) == 0
+    assert hip.query('tv_gemm_f32_workspace_bytes', 4096, 1024, 1000) == 8 * 32 * image
+    full = hip.query('tv_gemm_f32_workspace_bytes', 51200, 1000, 1000)
+    assert full > 8 * 32 * image and (full - 8 * 32 * image) % (128 * 128 * 4) == 0
+    assert hip.query('tv_gemm_f32_workspace_bytes', 1000, 1000, 51200) >= 2 * 1000 * 1000 * 4
 
 
 def test_host_side_validation_without_gpu():
