@@ -603,7 +603,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
 
   __syncthreads();                                 // tile 0 is in buffer 0
-  for (int it = 0; it < nt; ++it) {
+  // a partial last tile of at most 16 k holds nothing in its second k-step (K = 1000: 8 of 32)
+  const int nfull = (rem > 0 && rem <= 16) ? nt - 1 : nt;
+  for (int it = 0; it < nfull; ++it) {
     const char *As = smem + (it & 1) * (2 * OPERAND_BYTES), *Bs = As + OPERAND_BYTES;
     // Both 16-deep k-steps (a partial tile's missing k were stored as zeros).  Four fragment
     // sets (A0, B0, B1, A1 of a step; 3 planes = 12 registers each) are refilled as soon as
@@ -640,6 +642,19 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
     mma6(S, R, hi[1][1], lo[1][1]);
     __syncthreads();                               // buffer it&1 may be refilled, (it+1)&1 is ready
+  }
+  if (nfull < nt) {                                // first k-step only
+    const char *As = smem + (nfull & 1) * (2 * OPERAND_BYTES), *Bs = As + OPERAND_BYTES;
+    bf16x8 P[3], Q[3], R[3], S[3];
+    read_set(As, wm * 64, lane, 0, P);
+    read_set(Bs, wn * 64, lane, 0, Q);
+    read_set(Bs, wn * 64 + 32, lane, 0, R);
+    read_set(As, wm * 64 + 32, lane, 0, S);
+    mma6(P, Q, hi[0][0], lo[0][0]);
+    mma6(P, R, hi[0][1], lo[0][1]);
+    mma6(S, R, hi[1][1], lo[1][1]);
+    mma6(S, Q, hi[1][0], lo[1][0]);
+    __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
