@@ -379,9 +379,15 @@ def main():
             if name in kernel_summary:
                 ideal_s += kernel_summary[name][1] / peak
                 attributed_ms += kernel_summary[name][2]
+        # (the same sum with the GEMM priced at the fp32 matrix peak of 157.3 TFLOP/s, the bound
+        # of the kernel it replaced, is kept beside it so that rounds can be compared)
+        ideal_f32 = ideal_s
+        if 'gemm_f32' in kernel_summary:
+            ideal_f32 += kernel_summary['gemm_f32'][1] * (1.0 / 157.3e12 - 1.0 / (GEMM_PEAK_TFLOPS * 1e12))
         step_roof = {'ideal_ms_per_step': 1e3 * ideal_s / args.steps,
                      'measured_ms_per_step': 1e3 * elapsed / args.steps,
                      'frac': ideal_s / elapsed,
+                     'frac_with_gemm_at_fp32_matrix_peak': ideal_f32 / elapsed,
                      'attributed_share_of_step': attributed_ms * 1e-3 / elapsed,
                      'covers': 'gemm_f32 against bf16 MFMA peak / 6, gat_aggregate_fwd/bwd against '
                                'HBM; every other kernel counts as zero ideal time (lower bound). '

@@ -99,12 +99,21 @@ def ptr(t) -> Optional[int]:
 
 
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current HIP stream on the current device (the C-level accessor:
+    `torch.cuda.current_stream()` builds a Stream object per call, 15 us that a step of several
+    hundred launches pays several hundred times)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+_FUNCTIONS: Dict[str, object] = {}
 
 
 def call(name: str, *args) -> None:
     """Call an int-returning entry point on the current stream; raise on error."""
-    rc = getattr(lib(), name)(*args, stream())
+    fn = _FUNCTIONS.get(name)
+    if fn is None:
+        fn = _FUNCTIONS[name] = getattr(lib(), name)
+    rc = fn(*args, stream())
     if rc != 0:
         msg = lib().tv_last_error().decode('utf-8', 'replace')
         raise HipLibraryError(f'{name} failed ({rc}): {msg}')
