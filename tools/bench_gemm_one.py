@@ -24,6 +24,8 @@ elif which == 'dx':
 else:
     a, b, ta, tb = torch.randn(m, 1000, device=dev), torch.randn(m, 1000, device=dev), True, False
     m, n, k = 1000, 1000, 51200
+if len(sys.argv) > 3 and sys.argv[3] == 'zero':      # same kernel, no switching activity in the data
+    a.zero_(); b.zero_()
 c = torch.empty(m, n, device=dev)
 for _ in range(3):
     ops.gemm(a, b, ta, tb, out=c, act=act)

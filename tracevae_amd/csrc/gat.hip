@@ -736,13 +736,17 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   return TV_OK;
 }
 
+static inline int64_t pad4(int64_t floats) { return (floats + 3) & ~3ll; }
+
 extern "C" int64_t tv_gat_aggregate_bwd_workspace_bytes(int64_t rows_per_rep, int64_t n_rep,
                                                         int64_t heads, int64_t feats,
                                                         int64_t num_edges) {
   const int64_t rows = rows_per_rep * n_rep;
   const int64_t nblk = tv_stat_blocks_host(rows);
+  // dpre | der | partial, each segment a multiple of 4 floats: the partials are written 16 bytes
+  // at a time
   return (int64_t)sizeof(float) *
-         (n_rep * num_edges * heads + rows * heads + nblk * 3 * heads * feats);
+         (pad4(n_rep * num_edges * heads) + pad4(rows * heads) + nblk * 3 * heads * feats);
 }
 
 extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads,
@@ -774,8 +778,9 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   a.indptr = indptr; a.indices = indices; a.rev = rev; a.ft = ft; a.el = el; a.er = er;
   a.attn_l = attn_l; a.attn_r = attn_r; a.alpha_in = alpha; a.dout = dout; a.dft = dft;
   a.dpre = (float *)workspace;
-  a.der = a.dpre + n_rep * num_edges * heads;
-  a.partial = a.der + rows * heads;
+  a.der = a.dpre + pad4(n_rep * num_edges * heads);
+  a.partial = a.der + pad4(rows * heads);
+  TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gat_aggregate_bwd: workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const bool big = a.c4 > 256;
   {
