@@ -51,6 +51,8 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int STAGE_STRIDE = 72;                       // floats per staged output row (epilogue)
+constexpr int STAGE_BYTES = 4 * 32 * STAGE_STRIDE * 4;   // four consumer waves x 32 rows
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -67,6 +69,7 @@ struct GemmArgs {
   // 128x128 slabs [tile - tail_first][split], summed by gemm_tail_reduce_kernel
   int64_t tail_first, tail_splits, tail_kchunk;
   float *tail_slabs;
+  int64_t units;             // work units of the launch: (tile, split) pairs, walked by a persistent grid
   int accumulate;
   int a_vec, b_vec;          // 16-byte loads allowed for the operand (host-side dispatch)
   int c_vec;                 // 16-byte stores allowed for the output (ldc, N, base all % 4)
@@ -80,8 +83,7 @@ struct GemmArgs {
 };
 
 // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-// `smem` = the (now free) plane buffers: they hold a whole 64x64 block per consumer wave
-// (4 x 64 x 72 floats = 72 KB of the 96).
+// `smem` = the staging region behind the plane buffers: 32 x 72 floats per consumer wave.
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2][2], float *smem,
                                               int tile, int sp, bool tail, int nwg, int64_t m0,
                                               int64_t n0, int wave, int lane) {
@@ -105,31 +107,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2
   const bool plain = split || (!g.row_scale && !g.accumulate);
   if (plain && g.c_vec && m0 + BM <= g.M) {
     // all 128 rows of the tile exist and rows can be written 16 bytes per lane: the wave
-    // transposes its 64x64 block through LDS (the tile buffers are free now) and stores whole
-    // 256-byte row segments - 16 store instructions per lane instead of 64 scattered dwords.
-    // Row stride 72 floats: the two 32-lane halves of an accumulator register (rows r, r+4)
-    // land 32 banks apart.
-    constexpr int ES = 72;
-    constexpr int ROWS = 64;
-    float *ws = smem + wave * (ROWS * ES);          // (the caller's barrier freed the tile buffers)
+    // transposes its 64x64 block through its own staging region of LDS, 32 rows at a time, and
+    // stores whole 256-byte row segments - 16 store instructions per lane instead of 64
+    // scattered dwords.  Row stride 72 floats: the two 32-lane halves of an accumulator
+    // register (rows r, r+4) land 32 banks apart.  The region belongs to this wave alone and a
+    // wave's LDS accesses execute in order, so no barrier is involved: the producers are
+    // already filling the plane buffers for the next unit.
+    constexpr int ES = STAGE_STRIDE;
+    float *ws = smem + wave * (32 * ES);
     const int c = (lane & 15) * 4;
     const int64_t col = n0 + wn * 64 + c;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < g.N && !split && g.bias)
       bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
-    {
-      constexpr int half = 0;
 #pragma unroll
-      for (int i = 0; i < ROWS / 32; ++i)
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            ws[(i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * ES + j * 32 + xl] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r)
+          ws[(4 * kh + (r & 3) + 8 * (r >> 2)) * ES + j * 32 + xl] = acc[i][j][r];
       if (col < g.N) {                              // N % 4 == 0: the four columns exist together
-        float *o = out + (m0 + wm * 64 + half * ROWS + (lane >> 4)) * ldo + col;
+        float *o = out + (m0 + wm * 64 + i * 32 + (lane >> 4)) * ldo + col;
 #pragma unroll
-        for (int q = 0; q < ROWS / 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
           const float4 v = *reinterpret_cast<const float4 *>(&ws[(q * 4 + (lane >> 4)) * ES + c]);
           *reinterpret_cast<float4 *>(o + (int64_t)q * 4 * ldo) =
               make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
@@ -497,7 +498,62 @@ __device__ __forceinline__ void mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3],
   hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
 }
 
+// One work unit of a launch: an output tile, or one k-split of it.
+struct Unit {
+  int tile, sp, nwg;
+  bool tail;
+  int tn;
+  int64_t m0, n0, kbeg;
+  int ntf, rem, nt;            // full k-tiles, k of the partial one, k-tiles in all
+};
+
+// unit id -> (output tile, k-split).  Unit ids equal mod 8 walk a contiguous range of tiles (n
+// fastest): a persistent workgroup w takes units w, w + G, w + 2G, ... with G a multiple of 8, so
+// the workgroups of one XCD (hardware ids equal mod 8) share A panels in their own L2.
+__device__ __forceinline__ Unit decode_unit(const GemmArgs &g, int u) {
+  Unit x;
+  const int tail_units = g.tail_splits > 1;
+  const int nwg = tail_units ? (int)g.tail_first : (int)g.units;
+  int tile, sp;
+  int64_t kchunk;
+  x.tail = tail_units && u >= nwg;
+  if (x.tail) {
+    const int v = u - nwg;
+    tile = nwg + v / (int)g.tail_splits;
+    sp = v % (int)g.tail_splits;
+    kchunk = g.tail_kchunk;
+  } else {
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xcd = u & 7, idx = u >> 3;
+    const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    const int tiles = (int)(g.tiles_n * g.tiles_m);
+    tile = L % tiles;
+    sp = L / tiles;
+    kchunk = g.k_chunk;
+  }
+  x.nwg = nwg;
+  x.tile = __builtin_amdgcn_readfirstlane(tile);
+  x.sp = __builtin_amdgcn_readfirstlane(sp);
+  x.tn = __builtin_amdgcn_readfirstlane(x.tile % (int)g.tiles_n);
+  const int tm = __builtin_amdgcn_readfirstlane(x.tile / (int)g.tiles_n);
+  x.m0 = (int64_t)tm * BM;
+  x.n0 = (int64_t)x.tn * BN;
+  x.kbeg = x.sp * kchunk;
+  const int64_t kend = (x.kbeg + kchunk < g.K) ? (x.kbeg + kchunk) : g.K;
+  const int64_t klen = kend > x.kbeg ? kend - x.kbeg : 0;
+  x.ntf = __builtin_amdgcn_readfirstlane((int)(klen / BK));
+  x.rem = __builtin_amdgcn_readfirstlane((int)(klen - (int64_t)x.ntf * BK));
+  x.nt = x.ntf + (x.rem ? 1 : 0);
+  return x;
+}
+
 // 512 threads = four consumer waves (0-3) and four producer waves (4-7): see the head of the file.
+// The grid is PERSISTENT: one workgroup per CU walks the units of the launch, so while the
+// consumers add, transpose and store the tile they have finished (in an LDS region of their
+// own), the producers already load and split the first k-tiles of the next unit; the stores
+// drain behind the next unit's matrix instructions.  (With one workgroup per unit the epilogue
+// and the next workgroup's first loads were exposed on every CU at once, 14-20 % of a
+// 1000-deep product.)
 // Measured per k-tile at 51200 x 1000 x 1000 (in-kernel cycle stamps): consumers 1875 cycles
 // between barriers (1536 = 48 matrix instructions of 32 cycles), producers 2050-2230 for about 210
 // vector instructions, 12 LDS stores and 8 loads beside them - the vector side is the longer
@@ -507,61 +563,32 @@ template <int A_MODE, int B_MODE, int ACT>
 __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
   static_assert(ACT == 0 || (ACT == 1 && A_MODE != 2) || (ACT == 2 && B_MODE == 2), "prologue orientation");
   static_assert(B_MODE >= 0 && B_MODE <= 3 && A_MODE >= 0 && A_MODE <= 2, "load modes");
-  extern __shared__ __align__(16) char smem[];               // [buffer][A planes | B planes]
+  extern __shared__ __align__(16) char smem[];     // [buffer][A planes | B planes] | epilogue staging
   const bool producer = threadIdx.x >= 256;
   const int t = threadIdx.x & 255;
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-
-  // workgroup id -> (output tile, k-split): as gemm_f32_kernel
-  const int tail_units = g.tail_splits > 1;
-  const int nwg = tail_units ? (int)g.tail_first : (int)gridDim.x;
-  const int bid = blockIdx.x;
-  int tile, sp;
-  int64_t kchunk;
-  const bool tail = tail_units && bid >= nwg;
-  if (tail) {
-    const int u = bid - nwg;
-    tile = nwg + u / (int)g.tail_splits;
-    sp = u % (int)g.tail_splits;
-    kchunk = g.tail_kchunk;
-  } else {
-    const int q = nwg >> 3, rr = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int L = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-    const int tiles = (int)(g.tiles_n * g.tiles_m);
-    tile = L % tiles;
-    sp = L / tiles;
-    kchunk = g.k_chunk;
-  }
-  tile = __builtin_amdgcn_readfirstlane(tile);
-  sp = __builtin_amdgcn_readfirstlane(sp);
-  const int tn = __builtin_amdgcn_readfirstlane(tile % (int)g.tiles_n);
-  const int tm = __builtin_amdgcn_readfirstlane(tile / (int)g.tiles_n);
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-  const int64_t kbeg = sp * kchunk;
-  const int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
-  const int64_t klen = kend > kbeg ? kend - kbeg : 0;
-  const int ntf = __builtin_amdgcn_readfirstlane((int)(klen / BK));          // full k-tiles
-  const int rem = __builtin_amdgcn_readfirstlane((int)(klen - (int64_t)ntf * BK));
-  const int nt = ntf + (rem ? 1 : 0);
+  const int units = (int)g.units;
 
   if (producer) {
     using OperandA = Split<A_MODE, ACT == 1>;
     using OperandB = typename std::conditional<B_MODE == 3, PlaneTile, Split<B_MODE == 3 ? 0 : B_MODE, ACT == 2>>::type;
-    OperandA sa;
-    OperandB sb;
-    sa.init(g.A, g.lda, m0, g.M, kbeg, t);
-    if constexpr (B_MODE == 3) sb.init(g.b_planes, g.b_ktiles, tn, kbeg, t);
-    else sb.init(g.B, g.ldb, n0, g.N, kbeg, t);
-    sa.init_act(g.act_scale, g.act_shift, g.act_slope, m0, g.M, kbeg);
-    sb.init_act(g.act_scale, g.act_shift, g.act_slope, n0, g.N, kbeg);
-    typename OperandA::Regs ra0, ra1;
-    typename OperandB::Regs rb0, rb1;
     constexpr int TILE_LOADS = OperandA::LOADS + OperandB::LOADS;
-    // tile `it` lives in set it&1; the loads of tile it+2 are issued as soon as tile it is split,
-    // so when tile it is needed only the TILE_LOADS loads of tile it+1 are younger than its own
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+      const Unit x = decode_unit(g, u);
+      const int ntf = x.ntf, rem = x.rem, nt = x.nt;
+      OperandA sa;
+      OperandB sb;
+      sa.init(g.A, g.lda, x.m0, g.M, x.kbeg, t);
+      if constexpr (B_MODE == 3) sb.init(g.b_planes, g.b_ktiles, x.tn, x.kbeg, t);
+      else sb.init(g.B, g.ldb, x.n0, g.N, x.kbeg, t);
+      sa.init_act(g.act_scale, g.act_shift, g.act_slope, x.m0, g.M, x.kbeg);
+      sb.init_act(g.act_scale, g.act_shift, g.act_slope, x.n0, g.N, x.kbeg);
+      typename OperandA::Regs ra0, ra1;
+      typename OperandB::Regs rb0, rb1;
+      // tile `it` lives in set it&1; the loads of tile it+2 are issued as soon as tile it is split,
+      // so when tile it is needed only the TILE_LOADS loads of tile it+1 are younger than its own
 #define TV_LOAD(IT, RA, RB)                                                       \
   do {                                                                            \
     if ((IT) < ntf) { sa.load(RA); sb.load(RB); }                                 \
@@ -582,89 +609,97 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
     }                                                                             \
     __syncthreads();                                                              \
   } while (0)
-    TV_LOAD(0, ra0, rb0);
-    TV_LOAD(1, ra1, rb1);
-    // nt + 1 barriers, like the consumers
-    for (int it = 0; it <= nt; it += 2) {
-      TV_STAGE(it, ra0, rb0);
-      if (it + 1 <= nt) TV_STAGE(it + 1, ra1, rb1);
-    }
+      TV_LOAD(0, ra0, rb0);
+      TV_LOAD(1, ra1, rb1);
+      // nt + 1 barriers per unit, like the consumers.  The last one follows the consumers' last
+      // read of a plane buffer, so the next unit's tile 0 may be written straight after it.
+      for (int it = 0; it <= nt; it += 2) {
+        TV_STAGE(it, ra0, rb0);
+        if (it + 1 <= nt) TV_STAGE(it + 1, ra1, rb1);
+      }
 #undef TV_STAGE
 #undef TV_LOAD
+    }
     return;
   }
 
-  f32x16 hi[2][2], lo[2][2];
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const Unit x = decode_unit(g, u);
+    const int rem = x.rem, nt = x.nt;
+    f32x16 hi[2][2], lo[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
 
-  __syncthreads();                                 // tile 0 is in buffer 0
-  // a partial last tile of at most 16 k holds nothing in its second k-step (K = 1000: 8 of 32)
-  const int nfull = (rem > 0 && rem <= 16) ? nt - 1 : nt;
-  for (int it = 0; it < nfull; ++it) {
-    const char *As = smem + (it & 1) * (2 * OPERAND_BYTES), *Bs = As + OPERAND_BYTES;
-    // Both 16-deep k-steps (a partial tile's missing k were stored as zeros).  Four fragment
-    // sets (A0, B0, B1, A1 of a step; 3 planes = 12 registers each) are refilled as soon as
-    // their last use has been issued, one or two stages (6-12 MFMAs, 200-400 cycles) ahead of
-    // their next use; the stage order is pinned, so the matrix pipe only waits for LDS at the
-    // head of a tile.
-    //   stage : 1      2      3      4    | 5       6      7      8
-    //   tile  : (0,0)  (0,1)  (1,1)  (1,0)| (0,1)   (0,0)  (1,0)  (1,1)
-    //   sets  : P Q    P R    S R    S Q  | P R     P Q    S Q    S R
-    //   refill: -      -      P=A0'  R=B1'| Q=B0',S=A1'
-    bf16x8 P[3], Q[3], R[3], S[3];
-    read_set(As, wm * 64, lane, 0, P);           // A0 step 0
-    read_set(Bs, wn * 64, lane, 0, Q);           // B0 step 0
-    read_set(Bs, wn * 64 + 32, lane, 0, R);      // B1 step 0
-    read_set(As, wm * 64 + 32, lane, 0, S);      // A1 step 0
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(P, Q, hi[0][0], lo[0][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(P, R, hi[0][1], lo[0][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set(As, wm * 64, lane, 1, P);           // A0 step 1
-    mma6(S, R, hi[1][1], lo[1][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set(Bs, wn * 64 + 32, lane, 1, R);      // B1 step 1
-    mma6(S, Q, hi[1][0], lo[1][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set(Bs, wn * 64, lane, 1, Q);           // B0 step 1
-    read_set(As, wm * 64 + 32, lane, 1, S);      // A1 step 1
-    mma6(P, R, hi[0][1], lo[0][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(P, Q, hi[0][0], lo[0][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(S, Q, hi[1][0], lo[1][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(S, R, hi[1][1], lo[1][1]);
-    __syncthreads();                               // buffer it&1 may be refilled, (it+1)&1 is ready
-  }
-  if (nfull < nt) {                                // first k-step only
-    const char *As = smem + (nfull & 1) * (2 * OPERAND_BYTES), *Bs = As + OPERAND_BYTES;
-    bf16x8 P[3], Q[3], R[3], S[3];
-    read_set(As, wm * 64, lane, 0, P);
-    read_set(Bs, wn * 64, lane, 0, Q);
-    read_set(Bs, wn * 64 + 32, lane, 0, R);
-    read_set(As, wm * 64 + 32, lane, 0, S);
-    mma6(P, Q, hi[0][0], lo[0][0]);
-    mma6(P, R, hi[0][1], lo[0][1]);
-    mma6(S, R, hi[1][1], lo[1][1]);
-    mma6(S, Q, hi[1][0], lo[1][0]);
-    __syncthreads();
-  }
+    __syncthreads();                               // tile 0 is in buffer 0
+    // a partial last tile of at most 16 k holds nothing in its second k-step (K = 1000: 8 of 32)
+    const int nfull = (rem > 0 && rem <= 16) ? nt - 1 : nt;
+    for (int it = 0; it < nfull; ++it) {
+      const char *As = smem + (it & 1) * (2 * OPERAND_BYTES), *Bs = As + OPERAND_BYTES;
+      // Both 16-deep k-steps (a partial tile's missing k were stored as zeros).  Four fragment
+      // sets (A0, B0, B1, A1 of a step; 3 planes = 12 registers each) are refilled as soon as
+      // their last use has been issued, one or two stages (6-12 MFMAs, 200-400 cycles) ahead of
+      // their next use; the stage order is pinned, so the matrix pipe only waits for LDS at the
+      // head of a tile.
+      //   stage : 1      2      3      4    | 5       6      7      8
+      //   tile  : (0,0)  (0,1)  (1,1)  (1,0)| (0,1)   (0,0)  (1,0)  (1,1)
+      //   sets  : P Q    P R    S R    S Q  | P R     P Q    S Q    S R
+      //   refill: -      -      P=A0'  R=B1'| Q=B0',S=A1'
+      bf16x8 P[3], Q[3], R[3], S[3];
+      read_set(As, wm * 64, lane, 0, P);           // A0 step 0
+      read_set(Bs, wn * 64, lane, 0, Q);           // B0 step 0
+      read_set(Bs, wn * 64 + 32, lane, 0, R);      // B1 step 0
+      read_set(As, wm * 64 + 32, lane, 0, S);      // A1 step 0
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(P, Q, hi[0][0], lo[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(P, R, hi[0][1], lo[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(As, wm * 64, lane, 1, P);           // A0 step 1
+      mma6(S, R, hi[1][1], lo[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(Bs, wn * 64 + 32, lane, 1, R);      // B1 step 1
+      mma6(S, Q, hi[1][0], lo[1][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(Bs, wn * 64, lane, 1, Q);           // B0 step 1
+      read_set(As, wm * 64 + 32, lane, 1, S);      // A1 step 1
+      mma6(P, R, hi[0][1], lo[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(P, Q, hi[0][0], lo[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(S, Q, hi[1][0], lo[1][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(S, R, hi[1][1], lo[1][1]);
+      __syncthreads();                             // buffer it&1 may be refilled, (it+1)&1 is ready
+    }
+    if (nfull < nt) {                              // first k-step only
+      const char *As = smem + (nfull & 1) * (2 * OPERAND_BYTES), *Bs = As + OPERAND_BYTES;
+      bf16x8 P[3], Q[3], R[3], S[3];
+      read_set(As, wm * 64, lane, 0, P);
+      read_set(Bs, wn * 64, lane, 0, Q);
+      read_set(Bs, wn * 64 + 32, lane, 0, R);
+      read_set(As, wm * 64 + 32, lane, 0, S);
+      mma6(P, Q, hi[0][0], lo[0][0]);
+      mma6(P, R, hi[0][1], lo[0][1]);
+      mma6(S, R, hi[1][1], lo[1][1]);
+      mma6(S, Q, hi[1][0], lo[1][0]);
+      __syncthreads();
+    }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hi[i][j][r] += lo[i][j][r];
+        for (int r = 0; r < 16; ++r) hi[i][j][r] += lo[i][j][r];
 
-  // the producers are gone and every consumer is past the last barrier: the LDS is free
-  gemm_epilogue(g, hi, reinterpret_cast<float *>(smem), tile, sp, tail, nwg, m0, n0, wave, lane);
+    // every consumer is past the unit's last barrier; the plane buffers now belong to the
+    // producers again (next unit), the staging region behind them to this wave
+    gemm_epilogue(g, hi, reinterpret_cast<float *>(smem + 4 * OPERAND_BYTES), x.tile, x.sp, x.tail,
+                  x.nwg, x.m0, x.n0, wave, lane);
+  }
 }
 
 // second stage of split-K: out = epilogue(sum_s slab[s]) in slab order
@@ -872,8 +907,14 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   const int64_t nwg = g.tail_splits > 1 ? g.tail_first + (tiles - g.tail_first) * g.tail_splits
                                         : tiles * g.splits;
   TV_REQUIRE(nwg < (1ll << 31), "tv_gemm_f32: grid too large");
-  const dim3 grid((unsigned)nwg), block(512);
-  const size_t lds = 4 * (size_t)OPERAND_BYTES;             // two buffers x (A planes | B planes)
+  g.units = nwg;
+  // persistent grid: one workgroup per CU (a multiple of 8, so that a workgroup's units stay on
+  // the tile range of its XCD), or one per unit when there are fewer
+  int64_t resident = resident_workgroups() & ~7ll;
+  if (resident < 8) resident = 8;
+  const dim3 grid((unsigned)(nwg < resident ? nwg : resident)), block(512);
+  // two buffers x (A planes | B planes) + the consumers' epilogue staging
+  const size_t lds = 4 * (size_t)OPERAND_BYTES + STAGE_BYTES;
   int device = 0;
   TV_HIP(hipGetDevice(&device));
   // load mode of each operand: 0 = [x][k] 16-byte loads, 1 = [x][k] 4-byte loads, 2 = [k][x]
@@ -881,7 +922,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   const int bm = presplit ? 3 : trans_b ? (g.b_vec ? 0 : 1) : 2;
 #define TV_GEMM(AM, BM_, ACT)                                                                    \
   do {                                                                                           \
-    static bool raised[64] = {};  /* 96 KB of dynamic LDS: once per kernel and device */       \
+    static bool raised[64] = {};  /* 132 KB of dynamic LDS: once per kernel and device */       \
     if (!raised[device & 63]) {                                                                  \
       TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<AM, BM_, ACT>),     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
