@@ -51,8 +51,8 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int STAGE_STRIDE = 72;                       // floats per staged output row (epilogue)
-constexpr int STAGE_BYTES = 4 * 32 * STAGE_STRIDE * 4;   // four consumer waves x 32 rows
+constexpr int STAGE_BYTES = BM * BN * 4;               // the output tile, staged in LDS (64 KB)
+constexpr int STAGE_PIECES = 16;                       // ... and stored 4 rows per wave at a time
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -83,8 +83,9 @@ struct GemmArgs {
 };
 
 // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-// `smem` = the staging region behind the plane buffers: 32 x 72 floats per consumer wave.
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2][2], float *smem,
+// The direct forms (edge tiles, tail slabs, row scale / accumulate); whole tiles whose rows can be
+// written 16 bytes per lane go through the staged form below.
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2][2],
                                               int tile, int sp, bool tail, int nwg, int64_t m0,
                                               int64_t n0, int wave, int lane) {
   const int wm = wave >> 1, wn = wave & 1;
@@ -105,40 +106,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, f32x16 (&acc)[2
   float *out = split ? (g.slabs + (int64_t)sp * g.M * g.N) : g.C;
   const int64_t ldo = split ? g.N : g.ldc;
   const bool plain = split || (!g.row_scale && !g.accumulate);
-  if (plain && g.c_vec && m0 + BM <= g.M) {
-    // all 128 rows of the tile exist and rows can be written 16 bytes per lane: the wave
-    // transposes its 64x64 block through its own staging region of LDS, 32 rows at a time, and
-    // stores whole 256-byte row segments - 16 store instructions per lane instead of 64
-    // scattered dwords.  Row stride 72 floats: the two 32-lane halves of an accumulator
-    // register (rows r, r+4) land 32 banks apart.  The region belongs to this wave alone and a
-    // wave's LDS accesses execute in order, so no barrier is involved: the producers are
-    // already filling the plane buffers for the next unit.
-    constexpr int ES = STAGE_STRIDE;
-    float *ws = smem + wave * (32 * ES);
-    const int c = (lane & 15) * 4;
-    const int64_t col = n0 + wn * 64 + c;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < g.N && !split && g.bias)
-      bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ws[(4 * kh + (r & 3) + 8 * (r >> 2)) * ES + j * 32 + xl] = acc[i][j][r];
-      if (col < g.N) {                              // N % 4 == 0: the four columns exist together
-        float *o = out + (m0 + wm * 64 + i * 32 + (lane >> 4)) * ldo + col;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 v = *reinterpret_cast<const float4 *>(&ws[(q * 4 + (lane >> 4)) * ES + c]);
-          *reinterpret_cast<float4 *>(o + (int64_t)q * 4 * ldo) =
-              make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
-        }
-      }
-    }
-    return;
-  }
   if (plain && m0 + BM <= g.M) {
     // all 128 rows of the tile exist: stores are only predicated on the column of the lane
     float *o = out + (m0 + wm * 64 + 4 * kh) * ldo + n0 + wn * 64 + xl;
@@ -498,6 +465,42 @@ __device__ __forceinline__ void mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3],
   hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
 }
 
+// Staged epilogue.  A finished 64x64 block goes into the wave's own 16 KB of LDS behind the
+// plane buffers, transposed to row-major, and leaves it in 16 pieces of 4 rows (one 16-byte store
+// per lane each) that the wave issues one per k-tile DURING THE NEXT UNIT's matrix instructions.
+// Written out at once, the 64 KB tiles of all 256 CUs arrive at the memory system together and
+// the producers' loads for the next unit queue behind them: measured 10-16 % of the cycles of a
+// 51200 x 1000 x 1000 product (the same kernel with the stores removed).  The region belongs to
+// one wave and a wave's LDS accesses execute in order, so no barrier is involved.  Rows are 64
+// floats (all 64 banks); the two 32-lane halves of an accumulator register sit 4 rows apart and
+// swap 32-column halves (col ^ 32 when (row >> 2) & 1) to stay on different banks.
+struct Pending {
+  float *o;            // row (lane >> 4) of the block, the lane's 4 columns; nullptr columns: colok
+  float4 bv;           // bias of those columns
+  int64_t ldo;
+  bool colok;
+  int left;            // pieces not yet stored (0: nothing pending); piece q covers rows 4q .. 4q+3
+};
+
+__device__ __forceinline__ void stage_block(float *ws, f32x16 (&acc)[2][2], int lane) {
+  const int kh = lane >> 5, xl = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ws[(i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * 64 + ((j * 32 + xl) ^ (kh << 5))] = acc[i][j][r];
+}
+__device__ __forceinline__ float4 staged_piece(const float *ws, int q, int lane) {
+  return *reinterpret_cast<const float4 *>(&ws[(q * 4 + (lane >> 4)) * 64 + (((lane & 15) * 4) ^ ((q & 1) << 5))]);
+}
+__device__ __forceinline__ void store_piece(const Pending &p, int q, const float4 &v) {
+  if (p.colok)
+    *reinterpret_cast<float4 *>(p.o + (int64_t)q * 4 * p.ldo) =
+        make_float4(v.x + p.bv.x, v.y + p.bv.y, v.z + p.bv.z, v.w + p.bv.w);
+}
+
 // One work unit of a launch: an output tile, or one k-split of it.
 struct Unit {
   int tile, sp, nwg;
@@ -585,10 +588,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
       else sb.init(g.B, g.ldb, x.n0, g.N, x.kbeg, t);
       sa.init_act(g.act_scale, g.act_shift, g.act_slope, x.m0, g.M, x.kbeg);
       sb.init_act(g.act_scale, g.act_shift, g.act_slope, x.n0, g.N, x.kbeg);
-      typename OperandA::Regs ra0, ra1;
-      typename OperandB::Regs rb0, rb1;
-      // tile `it` lives in set it&1; the loads of tile it+2 are issued as soon as tile it is split,
-      // so when tile it is needed only the TILE_LOADS loads of tile it+1 are younger than its own
+      // Register sets: tile `it` lives in set it % DEPTH and the loads of tile it+DEPTH are issued
+      // as soon as tile it is split, so when tile it is needed only the loads of the (at most
+      // DEPTH-1) tiles after it are younger than its own.  Three tiles in flight: the latency of
+      // a load has a long tail while the memory system also takes the output tiles, and two
+      // k-tiles (2.5 us) of lookahead did not cover it.
+      constexpr int DEPTH = 3;
+      constexpr int YOUNGER2 = 2 * TILE_LOADS < 63 ? 2 * TILE_LOADS : 63;   // vmcnt holds 6 bits
+      typename OperandA::Regs ra[DEPTH];
+      typename OperandB::Regs rb[DEPTH];
 #define TV_LOAD(IT, RA, RB)                                                       \
   do {                                                                            \
     if ((IT) < ntf) { sa.load(RA); sb.load(RB); }                                 \
@@ -599,23 +607,26 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
   do {                                                                            \
     if ((IT) < nt) {                                                              \
       char *buf = smem + ((IT) & 1) * (2 * OPERAND_BYTES);                        \
-      if ((IT) + 1 < nt) wait_loads_but<TILE_LOADS>(); else wait_loads_but<0>();  \
+      if ((IT) + 2 < nt) wait_loads_but<YOUNGER2>();                              \
+      else if ((IT) + 1 < nt) wait_loads_but<TILE_LOADS>();                       \
+      else wait_loads_but<0>();                                                   \
       RA.landed(); RB.landed();                                                   \
       if ((IT) >= ntf) { sa.zero_tail(RA, rem, (IT)); sb.zero_tail(RB, rem, (IT)); } \
       sa.transform(RA); sb.transform(RB);                                         \
       sa.split_store(RA, buf);                                                    \
       sb.split_store(RB, buf + OPERAND_BYTES);                                    \
-      TV_LOAD((IT) + 2, RA, RB);                                                  \
+      TV_LOAD((IT) + DEPTH, RA, RB);                                              \
     }                                                                             \
     __syncthreads();                                                              \
   } while (0)
-      TV_LOAD(0, ra0, rb0);
-      TV_LOAD(1, ra1, rb1);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) TV_LOAD(d, ra[d], rb[d]);
       // nt + 1 barriers per unit, like the consumers.  The last one follows the consumers' last
       // read of a plane buffer, so the next unit's tile 0 may be written straight after it.
-      for (int it = 0; it <= nt; it += 2) {
-        TV_STAGE(it, ra0, rb0);
-        if (it + 1 <= nt) TV_STAGE(it + 1, ra1, rb1);
+      for (int it = 0; it <= nt; it += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+          if (it + d <= nt) TV_STAGE(it + d, ra[d], rb[d]);
       }
 #undef TV_STAGE
 #undef TV_LOAD
@@ -623,6 +634,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
     return;
   }
 
+  float *ws = reinterpret_cast<float *>(smem + 4 * OPERAND_BYTES) + wave * (64 * 64);
+  Pending pend;
+  pend.o = nullptr; pend.bv = make_float4(0.f, 0.f, 0.f, 0.f); pend.ldo = 0; pend.colok = false; pend.left = 0;
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const Unit x = decode_unit(g, u);
     const int rem = x.rem, nt = x.nt;
@@ -648,11 +662,16 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
       //   tile  : (0,0)  (0,1)  (1,1)  (1,0)| (0,1)   (0,0)  (1,0)  (1,1)
       //   sets  : P Q    P R    S R    S Q  | P R     P Q    S Q    S R
       //   refill: -      -      P=A0'  R=B1'| Q=B0',S=A1'
+      // Piece `it` of the previous unit's staged block is read with the first fragments and
+      // stored after stage 4.
+      const bool emit = it < pend.left;            // pieces go out in order: piece it at k-tile it
       bf16x8 P[3], Q[3], R[3], S[3];
+      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
       read_set(As, wm * 64, lane, 0, P);           // A0 step 0
       read_set(Bs, wn * 64, lane, 0, Q);           // B0 step 0
       read_set(Bs, wn * 64 + 32, lane, 0, R);      // B1 step 0
       read_set(As, wm * 64 + 32, lane, 0, S);      // A1 step 0
+      if (emit) pv = staged_piece(ws, it, lane);
       __builtin_amdgcn_sched_barrier(0);
       mma6(P, Q, hi[0][0], lo[0][0]);
       __builtin_amdgcn_sched_barrier(0);
@@ -664,6 +683,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
       read_set(Bs, wn * 64 + 32, lane, 1, R);      // B1 step 1
       mma6(S, Q, hi[1][0], lo[1][0]);
       __builtin_amdgcn_sched_barrier(0);
+      if (emit) store_piece(pend, it, pv);
       read_set(Bs, wn * 64, lane, 1, Q);           // B0 step 1
       read_set(As, wm * 64 + 32, lane, 1, S);      // A1 step 1
       mma6(P, R, hi[0][1], lo[0][1]);
@@ -688,6 +708,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
       mma6(S, Q, hi[1][0], lo[1][0]);
       __syncthreads();
     }
+    // a unit of fewer than 16 k-tiles leaves pieces of the previous block behind
+    for (int q = nfull; q < pend.left; ++q) store_piece(pend, q, staged_piece(ws, q, lane));
+    pend.left = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -697,9 +720,26 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
 
     // every consumer is past the unit's last barrier; the plane buffers now belong to the
     // producers again (next unit), the staging region behind them to this wave
-    gemm_epilogue(g, hi, reinterpret_cast<float *>(smem + 4 * OPERAND_BYTES), x.tile, x.sp, x.tail,
-                  x.nwg, x.m0, x.n0, wave, lane);
+    const bool split = g.splits > 1;
+    const bool plain = split || (!g.row_scale && !g.accumulate);
+    if (!x.tail && plain && g.c_vec && x.m0 + BM <= g.M) {
+      // all 128 rows of the tile exist and rows can be written 16 bytes per lane (N % 4 == 0: a
+      // lane's four columns exist together)
+      stage_block(ws, hi, lane);
+      const int64_t col = x.n0 + wn * 64 + (lane & 15) * 4;
+      float *out = split ? (g.slabs + (int64_t)x.sp * g.M * g.N) : g.C;
+      pend.ldo = split ? g.N : g.ldc;
+      pend.colok = col < g.N;
+      pend.o = out + (x.m0 + wm * 64 + (lane >> 4)) * pend.ldo + col;
+      pend.bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pend.colok && !split && g.bias)
+        pend.bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
+      pend.left = STAGE_PIECES;
+    } else {
+      gemm_epilogue(g, hi, x.tile, x.sp, x.tail, x.nwg, x.m0, x.n0, wave, lane);
+    }
   }
+  for (int q = 0; q < pend.left; ++q) store_piece(pend, q, staged_piece(ws, q, lane));
 }
 
 // second stage of split-K: out = epilogue(sum_s slab[s]) in slab order
@@ -922,7 +962,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   const int bm = presplit ? 3 : trans_b ? (g.b_vec ? 0 : 1) : 2;
 #define TV_GEMM(AM, BM_, ACT)                                                                    \
   do {                                                                                           \
-    static bool raised[64] = {};  /* 132 KB of dynamic LDS: once per kernel and device */       \
+    static bool raised[64] = {};  /* 160 KB of dynamic LDS: once per kernel and device */       \
     if (!raised[device & 63]) {                                                                  \
       TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<AM, BM_, ACT>),     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
