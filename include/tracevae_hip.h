@@ -227,7 +227,16 @@ int tv_colsum(int64_t rows, int64_t cols, const float *x, int64_t ldx, float *ou
  *     ep_scale/ep_shift != NULL : y = LeakyReLU_slope(out*ep_scale + ep_shift) written to
  *                             `out` instead (eval-mode BatchNorm + activation, :152-155).
  * tv_gat_aggregate_bwd: gradients w.r.t. ft, attn_l, attn_r, bias given d(out).
+ * tv_gat_fc_score_weight: weight_ext [H*F + pad4(2H), in] = [W ; A_l W ; A_r W ; 0], row H*F + h =
+ *   sum_f attn_l[h,f] W[h*F+f, :] (then attn_r): el = (x W^T) . attn_l = x . (W^T attn_l), so the
+ *   fc product of GATConv (gnn_layers.py:143, `self.fc(h)`) with weight_ext gives ft, el and er
+ *   in one pass [rows, H*F | H | H] and the rows of ft are not read again to form the scores.
+ * Row strides (in floats) let the aggregation read that layout in place: `ft_stride` of ft
+ *   (0 = H*F; a multiple of 4), `score_stride` of el / er (0 = H), `dft_stride` of dft (0 = H*F).
  * ---------------------------------------------------------------------------------- */
+int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_feats, const float *weight,
+                           const float *attn_l, const float *attn_r, float *weight_ext,
+                           void *stream);
 int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const float *ft,
                   const float *attn_l, const float *attn_r, float *el, float *er, void *stream);
 int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
@@ -235,7 +244,7 @@ int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
                          const float *el, const float *er, const float *bias, float *out,
                          float *alpha, float *stats_partial, const float *stats_row_weight,
                          const float *ep_scale, const float *ep_shift, float ep_slope,
-                         void *stream);
+                         int64_t ft_stride, int64_t score_stride, void *stream);
 int64_t tv_gat_aggregate_bwd_workspace_bytes(int64_t rows_per_rep, int64_t n_rep,
                                              int64_t heads, int64_t feats, int64_t num_edges);
 int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
@@ -243,7 +252,9 @@ int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
                          const int64_t *rev, const float *ft, const float *el, const float *er,
                          const float *attn_l, const float *attn_r, const float *alpha,
                          const float *dout, float *dft, float *dattn_l, float *dattn_r,
-                         float *dbias, void *workspace, int64_t workspace_bytes, void *stream);
+                         float *dbias, int64_t ft_stride, int64_t score_stride,
+                         int64_t dft_stride, void *workspace, int64_t workspace_bytes,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm over rows + LeakyReLU (tk.layers.BatchNorm = torch BatchNorm1d, then

@@ -242,6 +242,54 @@ def test_gat_conv_forward_backward(device, heads, feats, which):
     assert torch.equal(got2, got.detach())
 
 
+@pytest.mark.parametrize('heads,feats,k', [(2, 500, 1000), (2, 500, 41), (1, 64, 7), (4, 8, 50)])
+def test_gat_layer_with_scores_as_fc_columns(device, heads, feats, k):
+    """fc and the attention scores in ONE product ([ft | el | er] = x [W ; A_l W ; A_r W]^T,
+    `ops.linear_scores`) read in place by the aggregation, against the oracle's GATConv on h:
+    output and the gradients of x, W, attn_l, attn_r, bias; replicas + eval epilogue too."""
+    from oracle.model import gat_conv
+    from tracevae_amd import ops
+    db, ob = _graph(device)
+    graph = db.dec
+    src, dst = torch.as_tensor(ob['dec_src']), torch.as_tensor(ob['dec_dst'])
+    rows, hf = graph.num_rows, heads * feats
+    x = _rand(rows, k, seed=11)
+    w = _rand(hf, k, seed=12, scale=1.0 / k ** 0.5)
+    al, ar = _rand(1, heads, feats, seed=2, scale=0.3), _rand(1, heads, feats, seed=3, scale=0.3)
+    bias, g = _rand(hf, seed=4), _rand(rows, hf, seed=5)
+    xr, wr, alr, arr, br = (t.clone().double().requires_grad_(True) for t in (x, w, al, ar, bias))
+    ref = gat_conv(xr, src, dst, wr, alr, arr, br, heads).reshape(rows, -1)
+    ref.backward(g.double())
+
+    xd, wd, ald, ard, bd = (_dev(t, device).requires_grad_(True) for t in (x, w, al, ar, bias))
+    wx = ops.gat_fc_score_weight(wd.detach(), ald.detach(), ard.detach())
+    width = hf + ops.score_columns(heads)
+    assert wx.shape == (width, k) and torch.equal(wx[:hf], wd.detach())
+    assert not wx[hf + 2 * heads:].any()
+    a2 = al.reshape(heads, feats).double()
+    assert rel_err(wx[hf:hf + heads], torch.einsum('hf,hfk->hk', a2, w.double().reshape(heads, feats, k))) < TOL
+    fte = ops.linear_scores(xd, wd, ald, ard)
+    assert fte.shape == (rows, width)
+    got, _ = ops.gat_conv(fte, ald, ard, bd, graph, 1, want_stats=True)
+    got.backward(_dev(g, device))
+    assert rel_err(got, ref) < TOL
+    for a_, b_ in ((xd.grad, xr.grad), (wd.grad, wr.grad), (ald.grad, alr.grad), (ard.grad, arr.grad),
+                   (bd.grad, br.grad)):
+        assert rel_err(a_, b_) < TOL
+    # K replicas, no_grad, fused eval epilogue
+    K = 3
+    xk = _rand(K * rows, k, seed=21)
+    scale, shift = _rand(hf, seed=5), _rand(hf, seed=6)
+    refk = torch.cat([gat_conv(xk[i * rows:(i + 1) * rows].double(), src, dst, w.double(), al.double(),
+                               ar.double(), bias.double(), heads).reshape(rows, -1) for i in range(K)])
+    refk = F.leaky_relu(refk * scale + shift, 0.01)
+    with torch.no_grad():
+        ftk = ops.linear_scores(_dev(xk, device), wd, ald, ard)
+        gotk, _ = ops.gat_conv(ftk, ald, ard, bd, graph, K, ep_scale=_dev(scale, device),
+                               ep_shift=_dev(shift, device), ep_slope=0.01)
+    assert rel_err(gotk, refk) < TOL
+
+
 def test_gat_high_degree(device):
     """A star with more than 64 leaves exercises the multi-chunk edge loops."""
     from oracle.model import gat_conv

@@ -115,6 +115,9 @@ struct AggArgs {
   float ep_slope;
   // backward
   float *dpre, *der, *dft, *partial;
+  // row strides in floats: ft (H*F dense; H*F + 2H when el / er are two more column groups of the
+  // fc product, tv_gat_fc_score_weight), el / er (H dense), dft
+  int64_t ld_ft, ld_e, ld_dft;
 };
 
 template <int CH, int HT, bool STATS, bool EPILOGUE>
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
     }
     float erv[HT];
 #pragma unroll
-    for (int h = 0; h < HT; ++h) erv[h] = (h < H) ? a.er[r * H + h] : 0.f;
+    for (int h = 0; h < HT; ++h) erv[h] = (h < H) ? a.er[r * a.ld_e + h] : 0.f;
 
     float4 acc[CH];
 #pragma unroll
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
       // the first neighbour's row does not depend on the softmax: fetch it under the scores
       float4 first[CH];
       {
-        const float4 *srow0 = reinterpret_cast<const float4 *>(a.ft + __shfl(s, 0, 64) * HF);
+        const float4 *srow0 = reinterpret_cast<const float4 *>(a.ft + __shfl(s, 0, 64) * a.ld_ft);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int q = lane + 64 * c;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
       float e[HT], al[HT];
 #pragma unroll
       for (int h = 0; h < HT; ++h)
-        e[h] = (live && h < H) ? tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE) : -INFINITY;
+        e[h] = (live && h < H) ? tv_lrelu(a.el[s * a.ld_e + h] + erv[h], NEG_SLOPE) : -INFINITY;
 #pragma unroll
       for (int h = 0; h < HT; ++h) {
         const float mx = tv_wave_max(e[h]);
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
           aj0[h] = __shfl(al[h], jj, 64);
           aj1[h] = __shfl(al[h], jj + 1, 64);
         }
-        const float4 *srow0 = reinterpret_cast<const float4 *>(a.ft + sj0 * HF);
-        const float4 *srow1 = reinterpret_cast<const float4 *>(a.ft + sj1 * HF);
+        const float4 *srow0 = reinterpret_cast<const float4 *>(a.ft + sj0 * a.ld_ft);
+        const float4 *srow1 = reinterpret_cast<const float4 *>(a.ft + sj1 * a.ld_ft);
         float4 x0[CH], x1[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
         float aj[HT];
 #pragma unroll
         for (int h = 0; h < HT; ++h) aj[h] = __shfl(al[h], jj, 64);
-        const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * HF);
+        const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * a.ld_ft);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int q = lane + 64 * c;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
         const int64_t s = base + a.indices[p0 + j];
 #pragma unroll
         for (int h = 0; h < HT; ++h)
-          if (h < H) mx[h] = fmaxf(mx[h], tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE));
+          if (h < H) mx[h] = fmaxf(mx[h], tv_lrelu(a.el[s * a.ld_e + h] + erv[h], NEG_SLOPE));
       }
     }
 #pragma unroll
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
         const int64_t s = base + a.indices[p0 + j];
 #pragma unroll
         for (int h = 0; h < HT; ++h)
-          if (h < H) den[h] += expf(tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE) - mx[h]);
+          if (h < H) den[h] += expf(tv_lrelu(a.el[s * a.ld_e + h] + erv[h], NEG_SLOPE) - mx[h]);
       }
     }
 #pragma unroll
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
 #pragma unroll
         for (int h = 0; h < HT; ++h)
           if (h < H) {
-            al[h] = expf(tv_lrelu(a.el[s * H + h] + erv[h], NEG_SLOPE) - mx[h]) / den[h];
+            al[h] = expf(tv_lrelu(a.el[s * a.ld_e + h] + erv[h], NEG_SLOPE) - mx[h]) / den[h];
             if (a.alpha) a.alpha[(rep * a.num_edges + p0 + j) * H + h] = al[h];
           }
       }
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_
         float aj[HT];
 #pragma unroll
         for (int h = 0; h < HT; ++h) aj[h] = __shfl(al[h], jj, 64);
-        const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * HF);
+        const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * a.ld_ft);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           const int q = lane + 64 * c;
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
         float4 x[U][CH];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const float4 *srow = reinterpret_cast<const float4 *>(a.ft + __shfl(s, jj + u, 64) * HF);
+          const float4 *srow = reinterpret_cast<const float4 *>(a.ft + __shfl(s, jj + u, 64) * a.ld_ft);
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
             const int q = lane + 64 * c;
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
           if (h < H) {
             const float g = (deg > 64) ? a.dpre[(ebase + j) * H + h] : gkeep[h];
             const float al = a.alpha_in[(ebase + j) * H + h];
-            const float pre = a.el[s * H + h] + a.er[r * H + h];
+            const float pre = a.el[s * a.ld_e + h] + a.er[r * a.ld_e + h];
             const float dp = al * (g - sacc[h]) * (pre > 0.f ? 1.f : NEG_SLOPE);
             a.dpre[(ebase + j) * H + h] = dp;
             dsum[h] += dp;
@@ -597,8 +600,8 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kerne
       der[h] = (h < H) ? a.der[r * H + h] : 0.f;
     }
 
-    const float4 *frow = reinterpret_cast<const float4 *>(a.ft + r * HF);
-    float4 *orow = reinterpret_cast<float4 *>(a.dft + r * HF);
+    const float4 *frow = reinterpret_cast<const float4 *>(a.ft + r * a.ld_ft);
+    float4 *orow = reinterpret_cast<float4 *>(a.dft + r * a.ld_dft);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int q = lane + 64 * c;
@@ -670,6 +673,55 @@ int check_shape(const char *name, int64_t rows_per_rep, int64_t n_rep, int64_t h
   return TV_OK;
 }
 
+
+// row strides of ft and of el / er: 0 = dense; ft rows are read 16 bytes per lane
+int check_strides(const char *name, int64_t heads, int64_t feats, const float *ft,
+                  int64_t *ft_stride, int64_t *score_stride) {
+  if (*ft_stride == 0) *ft_stride = heads * feats;
+  if (*score_stride == 0) *score_stride = heads;
+  TV_REQUIRE(*ft_stride >= heads * feats && *ft_stride % 4 == 0, "%s: ft stride %lld must be a multiple of 4, >= heads*feats",
+             name, (long long)*ft_stride);
+  TV_REQUIRE((((uintptr_t)ft) & 15) == 0, "%s: ft must be 16-byte aligned", name);
+  TV_REQUIRE(*score_stride >= heads, "%s: score stride %lld < heads", name, (long long)*score_stride);
+  return TV_OK;
+}
+
+// W_ext = [W ; A_l W ; A_r W ; 0]: the fc weight [H*F, K] with 2H more rows (padded with zero
+// rows to a multiple of 4), row H*F + h =
+// sum_f attn_l[h, f] W[h*F + f, :] (then attn_r), so that el = ft . attn_l = x . (W^T attn_l)
+// and er come out of the fc product itself as 2H more columns and the rows of ft are not read
+// again to form them.  A workgroup owns 64 columns k of one head, 16 row groups deep.
+__global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F, int64_t K,
+                                                                   const float *__restrict__ W,
+                                                                   const float *__restrict__ al,
+                                                                   const float *__restrict__ ar,
+                                                                   float *__restrict__ Wx) {
+  __shared__ float part[2][16][64];
+  const int kx = threadIdx.x & 63, fg = threadIdx.x >> 6;      // 64 columns x 16 row groups
+  const int h = blockIdx.y;
+  const int64_t k = (int64_t)blockIdx.x * 64 + kx;
+  float sl = 0.f, sr = 0.f;
+  if (k < K) {
+    for (int f = fg; f < F; f += 16) {
+      const float w = W[((int64_t)h * F + f) * K + k];
+      Wx[((int64_t)h * F + f) * K + k] = w;
+      sl = fmaf(al[h * F + f], w, sl);
+      sr = fmaf(ar[h * F + f], w, sr);
+    }
+  }
+  part[0][fg][kx] = sl;
+  part[1][fg][kx] = sr;
+  __syncthreads();
+  if (fg < 2 && k < K) {                           // row groups summed in order
+    float t = 0.f;
+    for (int g = 0; g < 16; ++g) t += part[fg][g][kx];
+    Wx[((int64_t)H * F + fg * H + h) * K + k] = t;
+  }
+  // rows that pad 2H up to a multiple of 4 (rows of [ft | el | er] stay 16-byte aligned)
+  const int pad = ((2 * H + 3) & ~3) - 2 * H;
+  if (h == 0 && fg >= 2 && fg < 2 + pad && k < K) Wx[((int64_t)H * F + 2 * H + (fg - 2)) * K + k] = 0.f;
+}
+
 }  // namespace
 
 extern "C" int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const float *ft,
@@ -686,14 +738,28 @@ extern "C" int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const f
   return TV_OK;
 }
 
+extern "C" int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_feats,
+                                      const float *weight, const float *attn_l,
+                                      const float *attn_r, float *weight_ext, void *stream) {
+  if (int rc = check_shape("tv_gat_fc_score_weight", 0, 1, heads, feats)) return rc;
+  TV_REQUIRE(in_feats >= 1, "tv_gat_fc_score_weight: in_feats must be positive");
+  TV_REQUIRE(weight && attn_l && attn_r && weight_ext, "tv_gat_fc_score_weight: null pointer");
+  const dim3 grid((unsigned)tv_cdiv(in_feats, 64), (unsigned)heads), block(1024);
+  hipLaunchKernelGGL(gat_fc_score_weight_kernel, grid, block, 0, (hipStream_t)stream, (int)heads,
+                     (int)feats, in_feats, weight, attn_l, attn_r, weight_ext);
+  TV_LAUNCH_CHECK("tv_gat_fc_score_weight");
+  return TV_OK;
+}
+
 extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads,
                                     int64_t feats, const int64_t *indptr, const int64_t *indices,
                                     const float *ft, const float *el, const float *er,
                                     const float *bias, float *out, float *alpha,
                                     float *stats_partial, const float *stats_row_weight,
                                     const float *ep_scale, const float *ep_shift, float ep_slope,
-                                    void *stream) {
+                                    int64_t ft_stride, int64_t score_stride, void *stream) {
   if (int rc = check_shape("tv_gat_aggregate_fwd", rows_per_rep, n_rep, heads, feats)) return rc;
+  if (int rc = check_strides("tv_gat_aggregate_fwd", heads, feats, ft, &ft_stride, &score_stride)) return rc;
   const int64_t rows = rows_per_rep * n_rep;
   if (rows == 0) return TV_OK;
   TV_REQUIRE(indptr && indices && ft && el && er && bias && out,
@@ -709,6 +775,7 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   a.out = out; a.alpha = alpha; a.stats_partial = stats_partial;
   a.row_weight = stats_row_weight;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_slope = ep_slope;
+  a.ld_ft = ft_stride; a.ld_e = score_stride;
   // num_edges of one replica is only needed to index alpha; read back is avoided by
   // passing it through indptr on the host side of the caller: alpha is indexed with
   // rep * num_edges, and num_edges = indptr[rows_per_rep] is a device value.  With one
@@ -755,8 +822,13 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
                                     const float *el, const float *er, const float *attn_l,
                                     const float *attn_r, const float *alpha, const float *dout,
                                     float *dft, float *dattn_l, float *dattn_r, float *dbias,
+                                    int64_t ft_stride, int64_t score_stride, int64_t dft_stride,
                                     void *workspace, int64_t workspace_bytes, void *stream) {
   if (int rc = check_shape("tv_gat_aggregate_bwd", rows_per_rep, n_rep, heads, feats)) return rc;
+  if (int rc = check_strides("tv_gat_aggregate_bwd", heads, feats, ft, &ft_stride, &score_stride)) return rc;
+  if (dft_stride == 0) dft_stride = heads * feats;
+  TV_REQUIRE(dft_stride >= heads * feats && dft_stride % 4 == 0 && (((uintptr_t)dft) & 15) == 0,
+             "tv_gat_aggregate_bwd: dft rows must be 16-byte aligned, stride >= heads*feats");
   TV_REQUIRE(n_rep == 1, "tv_gat_aggregate_bwd: the backward pass runs on a single replica");
   const int64_t rows = rows_per_rep * n_rep;
   if (rows == 0) return TV_OK;
@@ -777,6 +849,7 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   a.H = (int)heads; a.F = (int)feats; a.c4 = (int)(HF / 4);
   a.indptr = indptr; a.indices = indices; a.rev = rev; a.ft = ft; a.el = el; a.er = er;
   a.attn_l = attn_l; a.attn_r = attn_r; a.alpha_in = alpha; a.dout = dout; a.dft = dft;
+  a.ld_ft = ft_stride; a.ld_e = score_stride; a.ld_dft = dft_stride;
   a.dpre = (float *)workspace;
   a.der = a.dpre + pad4(n_rep * num_edges * heads);
   a.partial = a.der + pad4(rows * heads);

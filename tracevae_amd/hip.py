@@ -98,6 +98,14 @@ def ptr(t) -> Optional[int]:
     return t.data_ptr()
 
 
+def ptr_rows(t) -> int:
+    """Device pointer of a 2-D tensor whose rows are contiguous but may be strided (a column
+    slice of a wider buffer); the caller passes `t.stride(0)` as the row stride."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError('a row-strided operand must be 2-D with contiguous rows')
+    return t.data_ptr()
+
+
 def stream() -> int:
     """Raw handle of torch's current HIP stream on the current device (the C-level accessor:
     `torch.cuda.current_stream()` builds a Stream object per call, 15 us that a step of several

@@ -219,12 +219,12 @@ class _DeferredBN(object):
     def __init__(self, x, stats, bn, row_weight, count):
         self.x, self.stats, self.bn, self.row_weight, self.count = x, stats, bn, row_weight, count
 
-    def linear(self, weight):
+    def linear(self, weight, attn_l=None, attn_r=None):
         bn = self.bn
         bn.count_batch()
         return ops.bn_lrelu_linear(self.x, bn.weight, bn.bias, weight, bn.running_mean,
                                    bn.running_var, bn.eps, bn.momentum, LRELU_SLOPE, self.stats,
-                                   self.row_weight, self.count)
+                                   self.row_weight, self.count, attn_l, attn_r)
 
 
 class GATConvAgg(nn.Module):
@@ -242,7 +242,11 @@ class GATConvAgg(nn.Module):
         (compact latency decoder); only the BatchNorm statistics see the difference.
         `defer`: in training mode return a `_DeferredBN` for the next GAT layer to consume."""
         g = self.gnn
-        ft = h.linear(g.fc.weight) if isinstance(h, _DeferredBN) else ops.linear(h, g.fc.weight)
+        # [ft | el | er]: the attention scores are 2H more columns of the fc product
+        if isinstance(h, _DeferredBN):
+            ft = h.linear(g.fc.weight, g.attn_l, g.attn_r)
+        else:
+            ft = ops.linear_scores(h, g.fc.weight, g.attn_l, g.attn_r)
         bn = self.normalization
         if bn is None:
             out, _ = ops.gat_conv(ft, g.attn_l, g.attn_r, g.bias, graph, n_rep)

@@ -96,6 +96,14 @@ def _check(t: torch.Tensor, name: str, dtype=_f32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _rows(t: torch.Tensor, name: str) -> torch.Tensor:
+    """A 2-D fp32 GPU operand whose rows may be strided (a column slice of a wider buffer)."""
+    if t.dim() == 2 and t.is_cuda and t.dtype == _f32 and t.stride(1) == 1 \
+            and t.stride(0) >= t.shape[1]:
+        return t
+    return _check(t, name)
+
+
 def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     if nbytes <= 0:
         return None
@@ -124,7 +132,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
     `act = (operand, scale, shift, slope)`: operand 1 (a, not transposed) or 2 (b, not
     transposed) goes through lrelu(v * scale[f] + shift[f]) on its way into the kernel
     (`tv_gemm_f32_act`)."""
-    a, b = _check(a, 'a'), _check(b, 'b')
+    a, b = _rows(a, 'a'), _rows(b, 'b')
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     n, kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
     if k != kb:
@@ -140,16 +148,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
     ws = _workspace(wsb, a.device)
     with TIMER.region('gemm_f32', 2.0 * m * n * k, (m, n, k, bool(trans_a), bool(trans_b))):
         if act is None:
-            hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr(a), a.stride(0),
-                     hip.ptr(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
+            hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a), a.stride(0),
+                     hip.ptr_rows(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
                      hip.ptr(row_scale), int(accumulate), hip.ptr(ws), wsb)
         else:
             operand, scale, shift, slope = act
             feats = k if operand == 1 else n
             if scale.numel() != feats or shift.numel() != feats:
                 raise ValueError(f'gemm: act scale / shift must have {feats} entries')
-            hip.call('tv_gemm_f32_act', int(trans_a), int(trans_b), m, n, k, hip.ptr(a),
-                     a.stride(0), hip.ptr(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
+            hip.call('tv_gemm_f32_act', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a),
+                     a.stride(0), hip.ptr_rows(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
                      hip.ptr(row_scale), int(accumulate), int(operand),
                      hip.ptr(_check(scale, 'act scale')), hip.ptr(_check(shift, 'act shift')),
                      float(slope), hip.ptr(ws), wsb)
@@ -194,6 +202,55 @@ class _Linear(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2)
         return dx, dw, db
+
+
+def score_columns(heads: int) -> int:
+    """Columns that el / er take behind ft: 2H, padded so that rows stay 16-byte aligned."""
+    return (2 * heads + 3) // 4 * 4
+
+
+def gat_fc_score_weight(weight, attn_l, attn_r):
+    """[W ; A_l W ; A_r W] (`tv_gat_fc_score_weight`): the fc weight of a GAT layer with 2H more
+    rows, so that el / er are 2H more columns of the fc product."""
+    weight = _check(weight, 'weight')
+    heads, feats = int(attn_l.shape[-2]), int(attn_l.shape[-1])
+    n, k = weight.shape
+    if n != heads * feats:
+        raise ValueError(f'gat_fc_score_weight: weight {tuple(weight.shape)} vs heads {heads} x feats {feats}')
+    out = torch.empty([n + score_columns(heads), k], dtype=_f32, device=weight.device)
+    hip.call('tv_gat_fc_score_weight', heads, feats, k, hip.ptr(weight),
+             hip.ptr(_check(attn_l, 'attn_l')), hip.ptr(_check(attn_r, 'attn_r')), hip.ptr(out))
+    return out
+
+
+class _LinearScores(Function):
+    """[ft | el | er] = x @ [W ; A_l W ; A_r W]^T: the fc product of a GAT layer with the attention
+    scores as 2H more columns.  The gradient that comes back is that of `_GATConv` with respect
+    to ft in the first H*F columns (el / er as functions of ft are already in it); the score
+    columns of it are never written or read."""
+
+    @staticmethod
+    def forward(ctx, x, weight, attn_l, attn_r):
+        x2 = _check(x, 'x')
+        weight = _check(weight, 'weight')
+        ctx.save_for_backward(x2, weight)
+        return gemm(x2, gat_fc_score_weight(weight, attn_l, attn_r), False, True)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dft = _check(dy, 'dy')[:, :weight.shape[0]]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dft, weight, False, False)
+        if ctx.needs_input_grad[1]:
+            dw = gemm(dft, x2, True, False)
+        return dx, dw, None, None
+
+
+def linear_scores(x, weight, attn_l, attn_r):
+    return _LinearScores.apply(x, weight, attn_l, attn_r)
 
 
 class _SkinnyLinear(Function):
@@ -312,16 +369,21 @@ class _GATConv(Function):
         ft = _check(ft, 'ft')
         heads, feats = int(attn_l.shape[-2]), int(attn_l.shape[-1])
         rows = ft.shape[0]
-        if rows != graph.num_rows * n_rep or ft.shape[1] != heads * feats:
+        hf = heads * feats
+        if rows != graph.num_rows * n_rep or ft.shape[1] not in (hf, hf + score_columns(heads)):
             raise ValueError(f'gat_conv: ft {tuple(ft.shape)} does not match graph rows '
                              f'{graph.num_rows} x {n_rep} / heads {heads} x feats {feats}')
         al, ar = _check(attn_l, 'attn_l').reshape(-1), _check(attn_r, 'attn_r').reshape(-1)
         bias = _check(bias, 'bias')
         dev = ft.device
-        el = torch.empty([rows, heads], dtype=_f32, device=dev)
-        er = torch.empty([rows, heads], dtype=_f32, device=dev)
-        hip.call('tv_gat_scores', rows, heads, feats, hip.ptr(ft), hip.ptr(al), hip.ptr(ar),
-                 hip.ptr(el), hip.ptr(er))
+        if ft.shape[1] == hf:
+            el = torch.empty([rows, heads], dtype=_f32, device=dev)
+            er = torch.empty([rows, heads], dtype=_f32, device=dev)
+            hip.call('tv_gat_scores', rows, heads, feats, hip.ptr(ft), hip.ptr(al), hip.ptr(ar),
+                     hip.ptr(el), hip.ptr(er))
+        else:
+            # [ft | el | er] from `linear_scores`: read in place
+            el, er = ft[:, hf:hf + heads], ft[:, hf + heads:hf + 2 * heads]
         if need_grad and n_rep != 1:
             raise ValueError('gat_conv: gradients are only available for a single graph replica')
         out = torch.empty([rows, heads * feats], dtype=_f32, device=dev)
@@ -331,15 +393,15 @@ class _GATConv(Function):
             stats = torch.empty([hip.query('tv_stat_blocks', rows), 2, heads * feats],
                                 dtype=_f32, device=dev)
         # algorithmic bytes: ft gathered once per in-edge + out written once (+ scores/indices)
-        hf = heads * feats
         work = 4.0 * hf * (graph.num_edges + graph.num_rows) * n_rep \
             + (8.0 * heads * (graph.num_edges + graph.num_rows) + 8.0 * graph.num_edges) * n_rep
         with TIMER.region('gat_aggregate_fwd', work):
             hip.call('tv_gat_aggregate_fwd', graph.num_rows, n_rep, heads, feats,
-                     hip.ptr(graph.indptr), hip.ptr(graph.indices), hip.ptr(ft), hip.ptr(el),
-                     hip.ptr(er), hip.ptr(bias), hip.ptr(out), hip.ptr(alpha), hip.ptr(stats),
+                     hip.ptr(graph.indptr), hip.ptr(graph.indices), hip.ptr(ft), hip.ptr_rows(el),
+                     hip.ptr_rows(er), hip.ptr(bias), hip.ptr(out), hip.ptr(alpha), hip.ptr(stats),
                      hip.ptr(stats_row_weight if want_stats else None),
-                     hip.ptr(ep_scale), hip.ptr(ep_shift), float(ep_slope))
+                     hip.ptr(ep_scale), hip.ptr(ep_shift), float(ep_slope),
+                     ft.stride(0), el.stride(0))
         if need_grad:
             ctx.save_for_backward(ft, el, er, alpha, al, ar)
             ctx.graph = graph
@@ -362,7 +424,7 @@ class _GATConv(Function):
         heads, feats = ctx.hf
         dout = _check(dout, 'dout')
         dev = ft.device
-        dft = torch.empty_like(ft)
+        dft = torch.empty_like(ft)          # score columns, if any, stay unwritten (`_LinearScores`)
         dal = torch.empty([heads * feats], dtype=_f32, device=dev)
         dar = torch.empty([heads * feats], dtype=_f32, device=dev)
         dbias = torch.empty([heads * feats], dtype=_f32, device=dev)
@@ -376,9 +438,9 @@ class _GATConv(Function):
         with TIMER.region('gat_aggregate_bwd', work):
             hip.call('tv_gat_aggregate_bwd', g.num_rows, 1, heads, feats, g.num_edges,
                      hip.ptr(g.indptr), hip.ptr(g.indices), hip.ptr(g.rev), hip.ptr(ft),
-                     hip.ptr(el), hip.ptr(er), hip.ptr(al), hip.ptr(ar), hip.ptr(alpha),
+                     hip.ptr_rows(el), hip.ptr_rows(er), hip.ptr(al), hip.ptr(ar), hip.ptr(alpha),
                      hip.ptr(dout), hip.ptr(dft), hip.ptr(dal), hip.ptr(dar), hip.ptr(dbias),
-                     hip.ptr(ws), wsb)
+                     ft.stride(0), el.stride(0), dft.stride(0), hip.ptr(ws), wsb)
         return (dft, dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape), dbias,
                 None, None, None, None, None, None, None, None)
 
@@ -451,7 +513,7 @@ class _BNLReLULinear(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, weight, running_mean, running_var, eps, momentum, slope,
-                stats, row_weight=None, count=None):
+                stats, row_weight=None, count=None, attn_l=None, attn_r=None):
         x, weight = _check(x, 'x'), _check(weight, 'weight')
         gamma, beta = _check(gamma, 'gamma'), _check(beta, 'beta')
         rows, cols = x.shape
@@ -469,7 +531,9 @@ class _BNLReLULinear(Function):
                  float(momentum), hip.ptr(mean), hip.ptr(rstd), hip.ptr(running_mean),
                  hip.ptr(running_var), hip.ptr(gamma), hip.ptr(beta), hip.ptr(scale),
                  hip.ptr(shift))
-        ft = gemm(x, weight, False, True, act=(1, scale, shift, slope))
+        # with attention vectors: [ft | el | er], as `_LinearScores`
+        w_fwd = weight if attn_l is None else gat_fc_score_weight(weight, attn_l, attn_r)
+        ft = gemm(x, w_fwd, False, True, act=(1, scale, shift, slope))
         ctx.save_for_backward(x, coeffs, gamma, beta, weight)
         ctx.slope = float(slope)
         ctx.row_weight, ctx.count = row_weight, count
@@ -481,7 +545,7 @@ class _BNLReLULinear(Function):
         x, coeffs, gamma, beta, weight = ctx.saved_tensors
         rows, cols = x.shape
         mean, rstd, scale, shift = (coeffs[i, :cols] for i in range(4))
-        dft = _check(dft, 'dft')
+        dft = _check(dft, 'dft')[:, :weight.shape[0]]
         dx = dgamma = dbeta = dw = None
         if ctx.needs_input_grad[3]:
             dw = gemm(dft, x, True, False, act=(2, scale, shift, ctx.slope))
@@ -495,15 +559,16 @@ class _BNLReLULinear(Function):
                      hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), ctx.slope,
                      hip.ptr(ctx.row_weight), ctx.count, hip.ptr(dx), hip.ptr(dgamma),
                      hip.ptr(dbeta), hip.ptr(ws), wsb)
-        return (dx, dgamma, dbeta, dw) + (None,) * 8
+        return (dx, dgamma, dbeta, dw) + (None,) * 10
 
 
 def bn_lrelu_linear(x, gamma, beta, weight, running_mean, running_var, eps: float,
                     momentum: float = 0.1, slope: float = 0.01, stats=None, row_weight=None,
-                    count=None):
-    """`linear(bn_lrelu(x, training=True), weight)` as one operator (see `_BNLReLULinear`)."""
+                    count=None, attn_l=None, attn_r=None):
+    """`linear(bn_lrelu(x, training=True), weight)` as one operator (see `_BNLReLULinear`); with
+    `attn_l` / `attn_r` the result is `[ft | el | er]` (`linear_scores`)."""
     return _BNLReLULinear.apply(x, gamma, beta, weight, running_mean, running_var, eps, momentum,
-                                slope, stats, row_weight, count)
+                                slope, stats, row_weight, count, attn_l, attn_r)
 
 
 class _AffineLReLU(Function):
