@@ -652,14 +652,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t nblk, int6
     }                                                                                            \
   } while (0)
 
-int64_t tv_gat_max_blocks() {
-  static int64_t v = 0;
-  if (v == 0) {
-    const char *e = getenv("TV_GAT_BLOCKS");
-    v = (e && atoll(e) > 0) ? atoll(e) : 2048;
-  }
-  return v;
-}
+// workgroups of the statistics-free aggregation (the row loop strides over the grid)
+int64_t tv_gat_max_blocks() { return 2048; }
 
 int check_shape(const char *name, int64_t rows_per_rep, int64_t n_rep, int64_t heads,
                 int64_t feats) {

@@ -825,8 +825,7 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
   p.tail_first = tiles; p.tail_splits = 1; p.tail_kchunk = p.k_chunk;
   p.slab_bytes = p.splits > 1 ? p.splits * m * n * (int64_t)sizeof(float) : 0;
   const int64_t slots = resident_workgroups();
-  static const bool tail_enabled = [] { const char *e = getenv("TV_GEMM_TAIL_SPLIT"); return !(e && e[0] == '0'); }();
-  if (tail_enabled && p.splits == 1 && tiles > slots && tiles < (1ll << 30)) {
+  if (p.splits == 1 && tiles > slots && tiles < (1ll << 30)) {
     const int64_t tail = tiles % slots;
     if (tail > 0) {
       int64_t ts = slots / tail;
@@ -858,11 +857,8 @@ int64_t choose_splits(int64_t m, int64_t n, int64_t k) {
   if (tiles >= 256 || k < 4 * BK) return 1;
   int64_t s = tv_cdiv(512, tiles);
   // a workgroup alone on its CU pays the full memory latency per k-tile, so few-tile problems
-  // are split deep: at least TV_GEMM_MIN_SPLIT_TILES (default 2) k-tiles per split
-  static const int64_t min_tiles = [] {
-    const char *e = getenv("TV_GEMM_MIN_SPLIT_TILES");
-    return (e && atoll(e) > 0) ? atoll(e) : 2ll;
-  }();
+  // are split deep: at least 2 k-tiles per split
+  constexpr int64_t min_tiles = 2;
   const int64_t kmax = k / (min_tiles * BK);
   if (s > kmax) s = kmax;
   if (s > 64) s = 64;

@@ -45,14 +45,7 @@ static inline int64_t tv_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // of a workgroup are combined in wave order, the workgroups in workgroup order)
 #define TV_STAT_MAX_BLOCKS 512
 #define TV_STAT_WAVES 8
-static inline int64_t tv_stat_max_blocks(void) {
-  static int64_t v = 0;
-  if (v == 0) {
-    const char *e = getenv("TV_STAT_BLOCKS");   // tuning knob; the default fills the chip once
-    v = (e && atoll(e) > 0) ? atoll(e) : TV_STAT_MAX_BLOCKS;
-  }
-  return v;
-}
+static inline int64_t tv_stat_max_blocks(void) { return TV_STAT_MAX_BLOCKS; }   // two per CU
 static inline int64_t tv_stat_blocks_host(int64_t rows) {
   int64_t b = tv_cdiv(rows, TV_STAT_WAVES);
   if (b < 1) b = 1;
