@@ -127,5 +127,14 @@ def call(name: str, *args) -> None:
         raise HipLibraryError(f'{name} failed ({rc}): {msg}')
 
 
+_QUERIES: Dict[tuple, int] = {}
+
+
 def query(name: str, *args) -> int:
-    return int(getattr(lib(), name)(*args))
+    """An int64-returning size query (workspace bytes, slot counts): pure functions of their
+    arguments, so the answers are kept."""
+    key = (name,) + args
+    v = _QUERIES.get(key)
+    if v is None:
+        v = _QUERIES[key] = int(getattr(lib(), name)(*args))
+    return v

@@ -104,10 +104,21 @@ def _rows(t: torch.Tensor, name: str) -> torch.Tensor:
     return _check(t, name)
 
 
+_WORKSPACES = {}
+
+
 def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
+    """Scratch for ONE library call (split-K slabs, partial sums, pre-split planes): nothing in
+    it outlives the call's own kernels and every launch goes to the device's current stream, so
+    the calls share one grow-only buffer per device instead of allocating per call."""
     if nbytes <= 0:
         return None
-    return torch.empty([(nbytes + 3) // 4], dtype=_f32, device=device)
+    key = (device.index, torch._C._cuda_getCurrentRawStream(device.index))
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty([max((nbytes + 3) // 4, 1 << 18)], dtype=_f32, device=device)
+        _WORKSPACES[key] = buf
+    return buf
 
 
 class DeviceGraph(object):

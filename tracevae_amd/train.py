@@ -89,12 +89,16 @@ class FlatParameters(object):
         self.names = [n for n, _ in ordered]
         self.slices: Dict[str, Tuple[int, int]] = {}
         self.tail_start = cur
+        # the gradient views are made once: slicing + reshaping the bucket per parameter and step
+        # cost the host 2 ms per step (177 parameters), a quarter of a batch-64 step
+        self.grad_views: Dict[str, torch.Tensor] = {}
         with torch.no_grad():
             for (name, p), start, size in zip(ordered, starts, sizes):
                 view = self.flat[start:start + size].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
-                p.grad = self.grad[start:start + size].view(p.shape)
+                self.grad_views[name] = self.grad[start:start + size].view(p.shape)
+                p.grad = self.grad_views[name]
                 self.slices[name] = (start, start + size)
                 if name.startswith(tail_prefix) and start < self.tail_start:
                     self.tail_start = start
@@ -112,7 +116,7 @@ class FlatParameters(object):
         for n, p in self.params.items():          # autograd may have replaced a view
             a, b = self.slices[n]
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * a:
-                p.grad = self.grad[a:b].view(p.shape)
+                p.grad = self.grad_views[n]
 
 
     # -- one backward pass without a per-parameter accumulate kernel ----------------------
@@ -128,8 +132,7 @@ class FlatParameters(object):
         self.grad.zero_()
         dst, src = [], []
         for n, p in self.params.items():
-            a, b = self.slices[n]
-            view = self.grad[a:b].view(p.shape)
+            view = self.grad_views[n]
             if p.grad is not None:
                 dst.append(view)
                 src.append(p.grad)
