@@ -1,6 +1,9 @@
-# A/B of the GEMM: tools/ab/libtv_old.so (a build of an earlier gemm_f32.hip, same C-ABI) against the tree's library
+# same-box A/B of GEMM builds: every tools/ab/libtv_*.so (builds of other gemm_f32.hip variants, same C-ABI)
 cd $GRAFT_REPO_ROOT
-for w in fwd dx dw fwdact dwact; do
-  TRACEVAE_HIP_LIB=$GRAFT_REPO_ROOT/tools/ab/libtv_old.so timeout -k 10 60 python tools/bench_gemm_one.py $w 100 2>/dev/null | sed 's/^/old /' || exit 1
-  timeout -k 10 60 python tools/bench_gemm_one.py $w 100 2>/dev/null | sed 's/^/new /' || exit 1
+for rep in 1 2; do
+for w in fwd dx dw fwdact; do
+  for lib in tools/ab/libtv_*.so; do
+    TRACEVAE_HIP_LIB=$GRAFT_REPO_ROOT/$lib timeout -k 10 60 python tools/bench_gemm_one.py $w 100 2>/dev/null | sed "s|^|$(basename $lib .so) |" || exit 1
+  done
+done
 done

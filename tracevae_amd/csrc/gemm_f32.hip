@@ -55,6 +55,7 @@ constexpr int STAGE_BYTES = BM * BN * 4;               // the output tile, stage
 constexpr int STAGE_PIECES = 16;                       // ... and stored 4 rows per wave at a time
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
   const float *A, *B;
@@ -170,7 +171,6 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {        // v_cv
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // The 16 fp32 elements a producer thread holds of one operand tile: element (row a, k j).
 // They are the destinations of global loads issued with inline assembly, so that the loads of
@@ -479,6 +479,7 @@ struct Pending {
   float4 bv;           // bias of those columns
   int64_t ldo;
   bool colok;
+  bool stream;         // final output (streams out) or split-K slab (read back at once)
   int left;            // pieces not yet stored (0: nothing pending); piece q covers rows 4q .. 4q+3
 };
 
@@ -496,9 +497,15 @@ __device__ __forceinline__ float4 staged_piece(const float *ws, int q, int lane)
   return *reinterpret_cast<const float4 *>(&ws[(q * 4 + (lane >> 4)) * 64 + (((lane & 15) * 4) ^ ((q & 1) << 5))]);
 }
 __device__ __forceinline__ void store_piece(const Pending &p, int q, const float4 &v) {
-  if (p.colok)
-    *reinterpret_cast<float4 *>(p.o + (int64_t)q * 4 * p.ldo) =
-        make_float4(v.x + p.bv.x, v.y + p.bv.y, v.z + p.bv.z, v.w + p.bv.w);
+  if (p.colok) {
+    const f32x4 o = {v.x + p.bv.x, v.y + p.bv.y, v.z + p.bv.z, v.w + p.bv.w};
+    f32x4 *dst = reinterpret_cast<f32x4 *>(p.o + (int64_t)q * 4 * p.ldo);
+    // the output streams out (non-temporal: it is far larger than the L2 and would push the
+    // operand panels out of it; +4 % on a 51200 x 1000 x 1000 product); split-K slabs are read
+    // back by the reduction kernel straight away and stay cacheable
+    if (p.stream) __builtin_nontemporal_store(o, dst);
+    else *dst = o;
+  }
 }
 
 // One work unit of a launch: an output tile, or one k-split of it.
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
 
   float *ws = reinterpret_cast<float *>(smem + 4 * OPERAND_BYTES) + wave * (64 * 64);
   Pending pend;
-  pend.o = nullptr; pend.bv = make_float4(0.f, 0.f, 0.f, 0.f); pend.ldo = 0; pend.colok = false; pend.left = 0;
+  pend.o = nullptr; pend.bv = make_float4(0.f, 0.f, 0.f, 0.f); pend.ldo = 0; pend.colok = false; pend.stream = false; pend.left = 0;
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const Unit x = decode_unit(g, u);
     const int rem = x.rem, nt = x.nt;
@@ -730,6 +737,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
       float *out = split ? (g.slabs + (int64_t)x.sp * g.M * g.N) : g.C;
       pend.ldo = split ? g.N : g.ldc;
       pend.colok = col < g.N;
+      pend.stream = !split;
       pend.o = out + (x.m0 + wm * 64 + (lane >> 4)) * pend.ldo + col;
       pend.bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pend.colok && !split && g.bias)
@@ -775,13 +783,13 @@ __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(GemmArgs g) {
       const float4 p = *reinterpret_cast<const float4 *>(&slab[s * (BM * BN) + rl * BN + c4]);
       v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
-    const int64_t row = tm * BM + rl;
+    const int64_t row = (int64_t)tm * BM + rl;
     if (row >= g.M) continue;
     const float rs = g.row_scale ? g.row_scale[row] : 1.0f;
     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t col = tn * BN + c4 + j;
+      const int64_t col = (int64_t)tn * BN + c4 + j;
       if (col < g.N) {
         float w = e[j] * rs;
         if (g.bias) w += g.bias[col];
