@@ -696,9 +696,25 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
   const int64_t k = (int64_t)blockIdx.x * 64 + kx;
   float sl = 0.f, sr = 0.f;
   if (k < K) {
-    for (int f = fg; f < F; f += 16) {
-      const float w = W[((int64_t)h * F + f) * K + k];
-      Wx[((int64_t)h * F + f) * K + k] = w;
+    // eight rows in flight per thread: with 16 x H x K/64 workgroups the kernel is bound by the
+    // latency of its loads, not by bytes
+    const float *wp = W + (int64_t)h * F * K + k;
+    float *xp = Wx + (int64_t)h * F * K + k;
+    int f = fg;
+    for (; f + 7 * 16 < F; f += 8 * 16) {
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = wp[(int64_t)(f + 16 * u) * K];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xp[(int64_t)(f + 16 * u) * K] = w[u];
+        sl = fmaf(al[h * F + f + 16 * u], w[u], sl);
+        sr = fmaf(ar[h * F + f + 16 * u], w[u], sr);
+      }
+    }
+    for (; f < F; f += 16) {
+      const float w = wp[(int64_t)f * K];
+      xp[(int64_t)f * K] = w;
       sl = fmaf(al[h * F + f], w, sl);
       sr = fmaf(ar[h * F + f], w, sr);
     }
