@@ -39,6 +39,34 @@ def test_gemm(device, m, n, k, ta, tb):
     assert rel_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize('m,n,k,ta,tb,strided', [
+    (40037, 1000, 1000, False, True, False),   # ~10 units per workgroup, partial last row tile, tail split
+    (40000, 1001, 1000, False, False, False),  # N % 4 != 0: the direct epilogue on every unit
+    (40000, 1000, 40, False, True, False),     # 2 k-tiles per unit: staged pieces flushed after the loop
+    (33000, 1004, 1000, False, True, True),    # output consumed in place by a strided reader
+    (1000, 1000, 40037, True, False, False),   # split-K slabs over two rounds of workgroups
+])
+def test_gemm_many_units_per_workgroup(device, m, n, k, ta, tb, strided):
+    """The GEMM grid is persistent: a workgroup walks several output tiles, and a finished tile
+    leaves through LDS in pieces stored during the next tile's k-loop.  Shapes with many rounds of
+    tiles, a partial last row tile, a tail split, short k-loops and edge epilogues between staged
+    ones, against the float64 product (computed on the GPU: torch's float64 GEMM)."""
+    from tracevae_amd import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(*((k, m) if ta else (m, k)), generator=g).to(device)
+    b = torch.randn(*((n, k) if tb else (k, n)), generator=g).to(device)
+    bias = torch.randn(n, generator=g).to(device)
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double()) + bias.double()
+    if strided:
+        wide = torch.full([m, n + 20], float('nan'), device=device)
+        got = ops.gemm(a, b, ta, tb, bias=bias, out=wide[:, :n])
+        assert torch.isnan(wide[:, n:]).all()             # nothing written beside the output
+    else:
+        got = ops.gemm(a, b, ta, tb, bias=bias)
+    assert rel_err(got, ref) < TOL
+    assert torch.equal(got, ops.gemm(a, b, ta, tb, bias=bias))      # bit-stable
+
+
 def test_gemm_split_k_and_accumulate(device):
     from tracevae_amd import ops
     # weight-gradient shape: small output, long reduction -> split-K path

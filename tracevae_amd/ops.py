@@ -149,6 +149,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
     if k != kb:
         raise ValueError(f'gemm: inner sizes differ: {k} vs {kb}')
     c = out if out is not None else torch.empty([m, n], dtype=_f32, device=a.device)
+    if out is not None and (tuple(out.shape) != (m, n) or _rows(out, 'out') is not out):
+        raise ValueError(f'gemm: out must be a [{m}, {n}] fp32 GPU tensor with contiguous rows')
     if m == 0 or n == 0:
         return c
     if k == 0:
@@ -160,7 +162,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
     with TIMER.region('gemm_f32', 2.0 * m * n * k, (m, n, k, bool(trans_a), bool(trans_b))):
         if act is None:
             hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a), a.stride(0),
-                     hip.ptr_rows(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
+                     hip.ptr_rows(b), b.stride(0), hip.ptr_rows(c), c.stride(0), hip.ptr(bias),
                      hip.ptr(row_scale), int(accumulate), hip.ptr(ws), wsb)
         else:
             operand, scale, shift, slope = act
@@ -168,7 +170,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
             if scale.numel() != feats or shift.numel() != feats:
                 raise ValueError(f'gemm: act scale / shift must have {feats} entries')
             hip.call('tv_gemm_f32_act', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a),
-                     a.stride(0), hip.ptr_rows(b), b.stride(0), hip.ptr(c), c.stride(0), hip.ptr(bias),
+                     a.stride(0), hip.ptr_rows(b), b.stride(0), hip.ptr_rows(c), c.stride(0), hip.ptr(bias),
                      hip.ptr(row_scale), int(accumulate), int(operand),
                      hip.ptr(_check(scale, 'act scale')), hip.ptr(_check(shift, 'act shift')),
                      float(slope), hip.ptr(ws), wsb)
