@@ -123,7 +123,25 @@ __global__ __launch_bounds__(256) void skinny_rowdot_kernel(int64_t rows, int64_
     float acc[SKN];
 #pragma unroll
     for (int j = 0; j < SKN; ++j) acc[j] = 0.f;
-    for (int64_t k = lane; k < K; k += 64) {
+    // four k per lane in flight: the loop is bound by the latency of its loads (a row of `a` and
+    // N short rows of W from the L2), not by bytes
+    int64_t k = lane;
+    for (; k + 3 * 64 < K; k += 4 * 64) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = a[r * K + k + 64 * u];
+#pragma unroll
+      for (int j = 0; j < SKN; ++j) {
+        if (j < N) {
+          float wv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) wv[u] = w[j * wsj + (k + 64 * u) * wsk];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] = fmaf(v[u], wv[u], acc[j]);
+        }
+      }
+    }
+    for (; k < K; k += 64) {
       const float v = a[r * K + k];
 #pragma unroll
       for (int j = 0; j < SKN; ++j)
