@@ -231,12 +231,21 @@ int tv_colsum(int64_t rows, int64_t cols, const float *x, int64_t ldx, float *ou
  *   sum_f attn_l[h,f] W[h*F+f, :] (then attn_r): el = (x W^T) . attn_l = x . (W^T attn_l), so the
  *   fc product of GATConv (gnn_layers.py:143, `self.fc(h)`) with weight_ext gives ft, el and er
  *   in one pass [rows, H*F | H | H] and the rows of ft are not read again to form the scores.
+ * tv_gat_fc_score_weight_bwd: its backward.  With `score_grad_columns` = 1 tv_gat_aggregate_bwd
+ *   writes [dft | del | der | 0] (dft WITHOUT the el / er terms, dattn_l / dattn_r untouched, may be
+ *   NULL): the two GEMMs of the fc layer with weight_ext then carry the score gradients to x and to
+ *   dweight_ext [H*F + pad4(2H), in] = [dft | del | der]^T x, and this call folds its derived rows
+ *   back: dW += attn_l (x) dWx[H*F+h] + attn_r (x) dWx[H*F+H+h] (in place, rows 0..H*F-1),
+ *   dattn_l[h,f] = <W[h*F+f], dWx[H*F+h]>.  The backward pass then does not read ft's rows again.
  * Row strides (in floats) let the aggregation read that layout in place: `ft_stride` of ft
  *   (0 = H*F; a multiple of 4), `score_stride` of el / er (0 = H), `dft_stride` of dft (0 = H*F).
  * ---------------------------------------------------------------------------------- */
 int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_feats, const float *weight,
                            const float *attn_l, const float *attn_r, float *weight_ext,
                            void *stream);
+int tv_gat_fc_score_weight_bwd(int64_t heads, int64_t feats, int64_t in_feats,
+                               const float *weight, const float *attn_l, const float *attn_r,
+                               float *dweight_ext, float *dattn_l, float *dattn_r, void *stream);
 int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const float *ft,
                   const float *attn_l, const float *attn_r, float *el, float *er, void *stream);
 int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
@@ -253,8 +262,8 @@ int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
                          const float *attn_l, const float *attn_r, const float *alpha,
                          const float *dout, float *dft, float *dattn_l, float *dattn_r,
                          float *dbias, int64_t ft_stride, int64_t score_stride,
-                         int64_t dft_stride, void *workspace, int64_t workspace_bytes,
-                         void *stream);
+                         int64_t dft_stride, int score_grad_columns, void *workspace,
+                         int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm over rows + LeakyReLU (tk.layers.BatchNorm = torch BatchNorm1d, then

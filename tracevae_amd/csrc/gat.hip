@@ -504,7 +504,11 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
 //   del[u]  = sum_p dpre[rev[p]]
 //   partial sums for dattn_l (del*ft), dattn_r (der*ft), dbias (dout)
 // ------------------------------------------------------------------------------------
-template <int CH, int HT>
+// SCORE_COLS: el / er are columns of the fc product ([ft | el | er], tv_gat_fc_score_weight), so
+// their gradients del / der leave as columns of dft ([dft | del | der | 0]) and reach x, W and the
+// attention vectors through the two GEMMs of the fc layer (tv_gat_fc_score_weight_bwd): this
+// pass then neither reads the rows of ft nor carries the attention-gradient partial sums.
+template <int CH, int HT, bool SCORE_COLS>
 __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
@@ -600,27 +604,48 @@ __global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kerne
       der[h] = (h < H) ? a.der[r * H + h] : 0.f;
     }
 
-    const float4 *frow = reinterpret_cast<const float4 *>(a.ft + r * a.ld_ft);
     float4 *orow = reinterpret_cast<float4 *>(a.dft + r * a.ld_dft);
+    if (SCORE_COLS) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int q = lane + 64 * c;
-      if (q < c4) {
-        const float dl = sel_head<HT>(del, hc[c]), dr = sel_head<HT>(der, hc[c]);
-        const float4 wl = reinterpret_cast<const float4 *>(a.attn_l)[q];
-        const float4 wr = reinterpret_cast<const float4 *>(a.attn_r)[q];
-        orow[q] = f4_fma(dr, wr, f4_fma(dl, wl, acc[c]));
-        const float4 f = frow[q];
-        pal[c] = f4_fma(dl, f, pal[c]);
-        par[c] = f4_fma(dr, f, par[c]);
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        if (q < c4) orow[q] = acc[c];
+      }
+      // del | der | zeros up to a multiple of 4 columns (the GEMMs read them all)
+      const int ncol = (2 * H + 3) & ~3;
+      if (lane < ncol) {
+        float v = 0.f;
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+          if (lane == h && h < H) v = del[h];
+          if (lane == H + h && h < H) v = der[h];
+        }
+        a.dft[r * a.ld_dft + HF + lane] = v;
+      }
+    } else {
+      const float4 *frow = reinterpret_cast<const float4 *>(a.ft + r * a.ld_ft);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        if (q < c4) {
+          const float dl = sel_head<HT>(del, hc[c]), dr = sel_head<HT>(der, hc[c]);
+          const float4 wl = reinterpret_cast<const float4 *>(a.attn_l)[q];
+          const float4 wr = reinterpret_cast<const float4 *>(a.attn_r)[q];
+          orow[q] = f4_fma(dr, wr, f4_fma(dl, wl, acc[c]));
+          const float4 f = frow[q];
+          pal[c] = f4_fma(dl, f, pal[c]);
+          par[c] = f4_fma(dr, f, par[c]);
+        }
       }
     }
   }
 
-  float4 v[2][CH];
+  if (!SCORE_COLS) {
+    float4 v[2][CH];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) { v[0][c] = pal[c]; v[1][c] = par[c]; }
-  block_col_reduce<2, CH>(lds, v, c4, a.partial + (int64_t)blockIdx.x * 3 * HF);
+    for (int c = 0; c < CH; ++c) { v[0][c] = pal[c]; v[1][c] = par[c]; }
+    block_col_reduce<2, CH>(lds, v, c4, a.partial + (int64_t)blockIdx.x * 3 * HF);
+  }
 }
 
 // out[s*C + c] = sum_b partial[b][s][c] in workgroup order (float64 accumulation)
@@ -630,10 +655,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t nblk, int6
                                                               int64_t C) {
   const int64_t i = (int64_t)blockIdx.x * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
   double tot[1];
-  tv_slot_sums<1>(partial, nblk, sc, 0, i, i < sc, tot);
-  if (threadIdx.x >= TV_SLOT_COLS || i >= sc) return;
   const int64_t s = i / C, c = i - s * C;
   float *o = (s == 0) ? o0 : (s == 1 ? o1 : o2);
+  tv_slot_sums<1>(partial, nblk, sc, 0, i, i < sc && o != nullptr, tot);   // a plane without an
+  if (threadIdx.x >= TV_SLOT_COLS || i >= sc) return;                      // output was not written
   if (o) o[c] = (float)tot[0];
 }
 
@@ -732,6 +757,37 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
   if (h == 0 && fg >= 2 && fg < 2 + pad && k < K) Wx[((int64_t)H * F + 2 * H + (fg - 2)) * K + k] = 0.f;
 }
 
+// Backward of tv_gat_fc_score_weight.  dWx [H*F + pad4(2H), K] is the weight gradient of the fc
+// product with the extended weight ([dft | del | der]^T x); rows H*F + h and H*F + H + h are the
+// gradients of the derived rows A_l W and A_r W:
+//   dW[h*F+f, :] = dWx[h*F+f, :] + attn_l[h,f] dWx[H*F+h, :] + attn_r[h,f] dWx[H*F+H+h, :]  (in place)
+//   dattn_l[h,f] = <W[h*F+f, :], dWx[H*F+h, :]>,  dattn_r likewise.
+// One wave per row of W.
+__global__ __launch_bounds__(256) void gat_fc_score_weight_bwd_kernel(int H, int F, int64_t K,
+                                                                      const float *__restrict__ W,
+                                                                      const float *__restrict__ al,
+                                                                      const float *__restrict__ ar,
+                                                                      float *__restrict__ dWx,
+                                                                      float *__restrict__ dal,
+                                                                      float *__restrict__ dar) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= (int64_t)H * F) return;
+  const int h = (int)(row / F);
+  const float a_l = al[row], a_r = ar[row];
+  const float *gl = dWx + ((int64_t)H * F + h) * K, *gr = dWx + ((int64_t)H * F + H + h) * K;
+  float sl = 0.f, sr = 0.f;
+  for (int64_t k = lane; k < K; k += 64) {
+    const float w = W[row * K + k], l = gl[k], r = gr[k];
+    sl = fmaf(w, l, sl);
+    sr = fmaf(w, r, sr);
+    dWx[row * K + k] += a_l * l + a_r * r;
+  }
+  sl = tv_wave_sum(sl);
+  sr = tv_wave_sum(sr);
+  if (lane == 0) { dal[row] = sl; dar[row] = sr; }
+}
+
 }  // namespace
 
 extern "C" int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const float *ft,
@@ -758,6 +814,21 @@ extern "C" int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_f
   hipLaunchKernelGGL(gat_fc_score_weight_kernel, grid, block, 0, (hipStream_t)stream, (int)heads,
                      (int)feats, in_feats, weight, attn_l, attn_r, weight_ext);
   TV_LAUNCH_CHECK("tv_gat_fc_score_weight");
+  return TV_OK;
+}
+
+extern "C" int tv_gat_fc_score_weight_bwd(int64_t heads, int64_t feats, int64_t in_feats,
+                                          const float *weight, const float *attn_l,
+                                          const float *attn_r, float *dweight_ext, float *dattn_l,
+                                          float *dattn_r, void *stream) {
+  if (int rc = check_shape("tv_gat_fc_score_weight_bwd", 0, 1, heads, feats)) return rc;
+  TV_REQUIRE(in_feats >= 1, "tv_gat_fc_score_weight_bwd: in_feats must be positive");
+  TV_REQUIRE(weight && attn_l && attn_r && dweight_ext && dattn_l && dattn_r,
+             "tv_gat_fc_score_weight_bwd: null pointer");
+  hipLaunchKernelGGL(gat_fc_score_weight_bwd_kernel, dim3((unsigned)tv_cdiv(heads * feats, 4)),
+                     dim3(256), 0, (hipStream_t)stream, (int)heads, (int)feats, in_feats, weight,
+                     attn_l, attn_r, dweight_ext, dattn_l, dattn_r);
+  TV_LAUNCH_CHECK("tv_gat_fc_score_weight_bwd");
   return TV_OK;
 }
 
@@ -833,18 +904,22 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
                                     const float *attn_r, const float *alpha, const float *dout,
                                     float *dft, float *dattn_l, float *dattn_r, float *dbias,
                                     int64_t ft_stride, int64_t score_stride, int64_t dft_stride,
-                                    void *workspace, int64_t workspace_bytes, void *stream) {
+                                    int score_grad_columns, void *workspace,
+                                    int64_t workspace_bytes, void *stream) {
   if (int rc = check_shape("tv_gat_aggregate_bwd", rows_per_rep, n_rep, heads, feats)) return rc;
   if (int rc = check_strides("tv_gat_aggregate_bwd", heads, feats, ft, &ft_stride, &score_stride)) return rc;
   if (dft_stride == 0) dft_stride = heads * feats;
+  TV_REQUIRE(!score_grad_columns || dft_stride >= heads * feats + ((2 * heads + 3) & ~3ll),
+             "tv_gat_aggregate_bwd: dft rows too short for the score-gradient columns");
   TV_REQUIRE(dft_stride >= heads * feats && dft_stride % 4 == 0 && (((uintptr_t)dft) & 15) == 0,
              "tv_gat_aggregate_bwd: dft rows must be 16-byte aligned, stride >= heads*feats");
   TV_REQUIRE(n_rep == 1, "tv_gat_aggregate_bwd: the backward pass runs on a single replica");
   const int64_t rows = rows_per_rep * n_rep;
   if (rows == 0) return TV_OK;
-  TV_REQUIRE(indptr && indices && rev && ft && el && er && attn_l && attn_r && alpha && dout &&
-                 dft && dattn_l && dattn_r && dbias,
+  TV_REQUIRE(indptr && indices && rev && ft && el && er && alpha && dout && dft && dbias,
              "tv_gat_aggregate_bwd: null pointer");
+  TV_REQUIRE(score_grad_columns || (attn_l && attn_r && dattn_l && dattn_r),
+             "tv_gat_aggregate_bwd: null attention vector / gradient");
   const int64_t need =
       tv_gat_aggregate_bwd_workspace_bytes(rows_per_rep, n_rep, heads, feats, num_edges);
   if (!workspace || workspace_bytes < need) {
@@ -876,11 +951,16 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   {
     const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
     const size_t ldsb = sizeof(float) * 2 * HF;
-    TV_GAT_LAUNCH(gat_bwd_node_kernel, grid, block, ldsb, s, a);
+    if (score_grad_columns) {
+      TV_GAT_LAUNCH(gat_bwd_node_kernel, grid, block, 0, s, a, , true);
+    } else {
+      TV_GAT_LAUNCH(gat_bwd_node_kernel, grid, block, ldsb, s, a, , false);
+    }
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(node)");
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(tv_slot_grid(3 * HF)), dim3(256), 0, s,
-                     nblk, 3 * HF, a.partial, dattn_l, dattn_r, dbias, HF);
+                     nblk, 3 * HF, a.partial, score_grad_columns ? nullptr : dattn_l,
+                     score_grad_columns ? nullptr : dattn_r, dbias, HF);
   TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(reduce)");
   return TV_OK;
 }

@@ -236,30 +236,44 @@ def gat_fc_score_weight(weight, attn_l, attn_r):
     return out
 
 
+def _score_weight_grads(dwx, weight, attn_l, attn_r):
+    """(dW, dattn_l, dattn_r) from the weight gradient of the extended fc product
+    (`tv_gat_fc_score_weight_bwd`; dW is the leading rows of `dwx`, updated in place)."""
+    heads, feats = int(attn_l.shape[-2]), int(attn_l.shape[-1])
+    n, k = weight.shape
+    dal = torch.empty([n], dtype=_f32, device=weight.device)
+    dar = torch.empty([n], dtype=_f32, device=weight.device)
+    hip.call('tv_gat_fc_score_weight_bwd', heads, feats, k, hip.ptr(weight),
+             hip.ptr(_check(attn_l, 'attn_l')), hip.ptr(_check(attn_r, 'attn_r')), hip.ptr(dwx),
+             hip.ptr(dal), hip.ptr(dar))
+    return dwx[:n], dal.reshape(attn_l.shape), dar.reshape(attn_r.shape)
+
+
 class _LinearScores(Function):
     """[ft | el | er] = x @ [W ; A_l W ; A_r W]^T: the fc product of a GAT layer with the attention
-    scores as 2H more columns.  The gradient that comes back is that of `_GATConv` with respect
-    to ft in the first H*F columns (el / er as functions of ft are already in it); the score
-    columns of it are never written or read."""
+    scores as 2H more columns.  The gradient that comes back from `_GATConv` is
+    [dft | del | der | 0] (dft without the el / er terms): the two GEMMs with the extended weight
+    carry the score gradients to x and W, and the attention vectors get theirs here."""
 
     @staticmethod
     def forward(ctx, x, weight, attn_l, attn_r):
         x2 = _check(x, 'x')
         weight = _check(weight, 'weight')
-        ctx.save_for_backward(x2, weight)
-        return gemm(x2, gat_fc_score_weight(weight, attn_l, attn_r), False, True)
+        wx = gat_fc_score_weight(weight, attn_l, attn_r)
+        ctx.save_for_backward(x2, weight, wx, attn_l, attn_r)
+        return gemm(x2, wx, False, True)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x2, weight = ctx.saved_tensors
-        dft = _check(dy, 'dy')[:, :weight.shape[0]]
-        dx = dw = None
+        x2, weight, wx, attn_l, attn_r = ctx.saved_tensors
+        dy = _check(dy, 'dy')
+        dx = dw = dal = dar = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(dft, weight, False, False)
-        if ctx.needs_input_grad[1]:
-            dw = gemm(dft, x2, True, False)
-        return dx, dw, None, None
+            dx = gemm(dy, wx, False, False)
+        if any(ctx.needs_input_grad[1:]):
+            dw, dal, dar = _score_weight_grads(gemm(dy, x2, True, False), weight, attn_l, attn_r)
+        return dx, dw, dal, dar
 
 
 def linear_scores(x, weight, attn_l, attn_r):
@@ -437,9 +451,14 @@ class _GATConv(Function):
         heads, feats = ctx.hf
         dout = _check(dout, 'dout')
         dev = ft.device
-        dft = torch.empty_like(ft)          # score columns, if any, stay unwritten (`_LinearScores`)
-        dal = torch.empty([heads * feats], dtype=_f32, device=dev)
-        dar = torch.empty([heads * feats], dtype=_f32, device=dev)
+        dft = torch.empty_like(ft)
+        # [ft | el | er] in, [dft | del | der | 0] out: the attention vectors get their gradients in
+        # the fc layer (`_LinearScores`, `_BNLReLULinear`)
+        cols = ft.shape[1] != heads * feats
+        dal = dar = None
+        if not cols:
+            dal = torch.empty([heads * feats], dtype=_f32, device=dev)
+            dar = torch.empty([heads * feats], dtype=_f32, device=dev)
         dbias = torch.empty([heads * feats], dtype=_f32, device=dev)
         wsb = hip.query('tv_gat_aggregate_bwd_workspace_bytes', g.num_rows, 1, heads, feats,
                         g.num_edges)
@@ -453,9 +472,10 @@ class _GATConv(Function):
                      hip.ptr(g.indptr), hip.ptr(g.indices), hip.ptr(g.rev), hip.ptr(ft),
                      hip.ptr_rows(el), hip.ptr_rows(er), hip.ptr(al), hip.ptr(ar), hip.ptr(alpha),
                      hip.ptr(dout), hip.ptr(dft), hip.ptr(dal), hip.ptr(dar), hip.ptr(dbias),
-                     ft.stride(0), el.stride(0), dft.stride(0), hip.ptr(ws), wsb)
-        return (dft, dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape), dbias,
-                None, None, None, None, None, None, None, None)
+                     ft.stride(0), el.stride(0), dft.stride(0), int(cols), hip.ptr(ws), wsb)
+        if not cols:
+            dal, dar = dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape)
+        return (dft, dal, dar, dbias, None, None, None, None, None, None, None, None)
 
 
 def gat_conv(ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int = 1,
@@ -545,9 +565,13 @@ class _BNLReLULinear(Function):
                  hip.ptr(running_var), hip.ptr(gamma), hip.ptr(beta), hip.ptr(scale),
                  hip.ptr(shift))
         # with attention vectors: [ft | el | er], as `_LinearScores`
-        w_fwd = weight if attn_l is None else gat_fc_score_weight(weight, attn_l, attn_r)
+        ctx.scores = attn_l is not None
+        w_fwd = gat_fc_score_weight(weight, attn_l, attn_r) if ctx.scores else weight
         ft = gemm(x, w_fwd, False, True, act=(1, scale, shift, slope))
-        ctx.save_for_backward(x, coeffs, gamma, beta, weight)
+        if ctx.scores:
+            ctx.save_for_backward(x, coeffs, gamma, beta, weight, w_fwd, attn_l, attn_r)
+        else:
+            ctx.save_for_backward(x, coeffs, gamma, beta, weight)
         ctx.slope = float(slope)
         ctx.row_weight, ctx.count = row_weight, count
         return ft
@@ -555,15 +579,20 @@ class _BNLReLULinear(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dft):
-        x, coeffs, gamma, beta, weight = ctx.saved_tensors
+        x, coeffs, gamma, beta, weight = ctx.saved_tensors[:5]
+        w_fwd = weight
+        if ctx.scores:
+            w_fwd, attn_l, attn_r = ctx.saved_tensors[5:]
         rows, cols = x.shape
         mean, rstd, scale, shift = (coeffs[i, :cols] for i in range(4))
-        dft = _check(dft, 'dft')[:, :weight.shape[0]]
-        dx = dgamma = dbeta = dw = None
-        if ctx.needs_input_grad[3]:
+        dft = _check(dft, 'dft')           # with scores: [dft | del | der | 0]
+        dx = dgamma = dbeta = dw = dal = dar = None
+        if ctx.needs_input_grad[3] or (ctx.scores and any(ctx.needs_input_grad[12:14])):
             dw = gemm(dft, x, True, False, act=(2, scale, shift, ctx.slope))
+            if ctx.scores:
+                dw, dal, dar = _score_weight_grads(dw, weight, attn_l, attn_r)
         if any(ctx.needs_input_grad[:3]):
-            dy = gemm(dft, weight, False, False)
+            dy = gemm(dft, w_fwd, False, False)
             dx = torch.empty_like(x)
             dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
             wsb = hip.query('tv_bn_lrelu_bwd_workspace_bytes', rows, cols)
@@ -572,7 +601,7 @@ class _BNLReLULinear(Function):
                      hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), ctx.slope,
                      hip.ptr(ctx.row_weight), ctx.count, hip.ptr(dx), hip.ptr(dgamma),
                      hip.ptr(dbeta), hip.ptr(ws), wsb)
-        return (dx, dgamma, dbeta, dw) + (None,) * 10
+        return (dx, dgamma, dbeta, dw) + (None,) * 8 + (dal, dar)
 
 
 def bn_lrelu_linear(x, gamma, beta, weight, running_mean, running_var, eps: float,
