@@ -186,6 +186,158 @@ __global__ __launch_bounds__(128 * NWN) void gemm_planes_kernel(const char *A, c
   }
 }
 
+
+// the two B images of a 256-column tile: 48 chunks of 1 KB over 8 waves, 3 per image and wave
+__device__ __forceinline__ void stage_b(const char *b_img, int64_t b_stride, char *buf, int wave, int lane) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  const unsigned voff = (unsigned)(wave * 3 * 1024 + lane * 16), loff = (unsigned)(wave * 3 * 1024);
+#pragma unroll
+  for (int img = 0; img < 2; ++img)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      __builtin_amdgcn_global_load_lds((const void *)(b_img + (int64_t)img * b_stride + voff + c * 1024),
+                                       (lds_void *)(buf + img * OPERAND_BYTES + loff + c * 1024), 16, 0, 0);
+}
+
+// Third form: B as ready-made plane images by LDS-DMA, A as fp32 rows split BY THE EIGHT
+// MULTIPLYING WAVES THEMSELVES between their matrix instructions (8 elements per thread and
+// k-tile: two 16-byte loads, ~44 vector instructions, three ds_write_b128), 128x256 tile, two
+// LDS buffers.  This is what the library could be rebuilt into without touching the data layout.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8_store(const f32x4 &u, const f32x4 &v, char *dst) {
+  unsigned pl[3][4];
+  const f32x4 *src[2] = {&u, &v};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float x0 = (*src[h])[0], x1 = (*src[h])[1], x2 = (*src[h])[2], x3 = (*src[h])[3];
+    const unsigned p01 = pack_bf16(x0, x1), p23 = pack_bf16(x2, x3);
+    const float e0 = x0 - __uint_as_float(p01 << 16), e1 = x1 - __uint_as_float(p01 & 0xffff0000u);
+    const float e2 = x2 - __uint_as_float(p23 << 16), e3 = x3 - __uint_as_float(p23 & 0xffff0000u);
+    const unsigned q01 = pack_bf16(e0, e1), q23 = pack_bf16(e2, e3);
+    const float f0 = e0 - __uint_as_float(q01 << 16), f1 = e1 - __uint_as_float(q01 & 0xffff0000u);
+    const float f2 = e2 - __uint_as_float(q23 << 16), f3 = e3 - __uint_as_float(q23 & 0xffff0000u);
+    pl[0][2 * h] = p01; pl[0][2 * h + 1] = p23;
+    pl[1][2 * h] = q01; pl[1][2 * h + 1] = q23;
+    pl[2][2 * h] = pack_bf16(f0, f1); pl[2][2 * h + 1] = pack_bf16(f2, f3);
+  }
+  // stores the compiler does not see: beside LDS-DMA in flight it would drain the DMAs
+  // (vmcnt(0)) before any ds_write of its own to the same array
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dst;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const u32x4 w = {pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+    if (p == 0) asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w) : "memory");
+    if (p == 1) asm volatile("ds_write_b128 %0, %1 offset:8192" ::"v"(addr), "v"(w) : "memory");
+    if (p == 2) asm volatile("ds_write_b128 %0, %1 offset:16384" ::"v"(addr), "v"(w) : "memory");
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_split_a_kernel(const float *A, int64_t lda, const char *B, float *C,
+                                                           int64_t M, int64_t N, int64_t ldc, int tiles_m,
+                                                           int tiles_n, int ktiles) {
+  extern __shared__ __align__(16) char smem[];        // 2 x (A image | 2 B images)
+  constexpr int BUF_BYTES = 3 * OPERAND_BYTES;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  tiles_n /= 2;
+  const int ntiles = tiles_m * tiles_n;
+  // A: thread owns row t>>2, k = 8*(t&3) .. +7 of every k-tile
+  const int arow = t >> 2, ap = 2 * (t & 3);
+  const unsigned a_lds = plane_offset(arow, ap);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int per = ntiles >> 3;
+    const int L = (tile & 7) * per + (tile >> 3);
+    const int tn = L % tiles_n, tm = L / tiles_n;
+    const char *a_base = reinterpret_cast<const char *>(A + (int64_t)tm * BM * lda);
+    const unsigned a_off = (unsigned)(((int64_t)arow * lda + 4 * ap) * 4);
+    const char *b_img = B + (int64_t)tn * 2 * ktiles * OPERAND_BYTES;
+    const int64_t bs = (int64_t)ktiles * OPERAND_BYTES;
+    f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+    f32x4 u, v;
+#define LAB_LOAD_A(KT)                                                                                   \
+  do {                                                                                                   \
+    const char *tp = a_base + (int64_t)(KT) * (BK * 4);                                                  \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(u) : "v"(a_off), "s"(tp));                      \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(v) : "v"(a_off), "s"(tp));            \
+  } while (0)
+#define LAB_STAGE_B(KT, BUF)                                                                             \
+  stage_b(b_img + (int64_t)(KT) * OPERAND_BYTES, bs, smem + (BUF) * BUF_BYTES + OPERAND_BYTES, wave, lane)
+    __builtin_amdgcn_s_barrier();                      // previous tile's last reads are done
+    LAB_STAGE_B(0, 0);
+    LAB_LOAD_A(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(u), "+v"(v));
+    split8_store(u, v, smem + a_lds);
+    if (ktiles > 1) LAB_LOAD_A(1);
+    for (int it = 0; it < ktiles; ++it) {
+      const bool more = it + 1 < ktiles;
+      // B(it) has landed (the two A loads of tile it+1 may still fly); own plane stores are done
+      if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (more) LAB_STAGE_B(it + 1, (it + 1) & 1);
+      const char *As = smem + (it & 1) * BUF_BYTES, *Bs = As + OPERAND_BYTES + (wn >> 1) * OPERAND_BYTES;
+      bf16x8 P[3], Q[3], R[3], S[3];
+      read_set(As, wm * 64, lane, 0, P);
+      read_set(Bs, (wn & 1) * 64, lane, 0, Q);
+      read_set(Bs, (wn & 1) * 64 + 32, lane, 0, R);
+      read_set(As, wm * 64 + 32, lane, 0, S);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(P, Q, hi[0][0], lo[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(P, R, hi[0][1], lo[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(As, wm * 64, lane, 1, P);
+      mma6(S, R, hi[1][1], lo[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(Bs, (wn & 1) * 64 + 32, lane, 1, R);
+      mma6(S, Q, hi[1][0], lo[1][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(Bs, (wn & 1) * 64, lane, 1, Q);
+      read_set(As, wm * 64 + 32, lane, 1, S);
+      if (more) {
+        // A(it+1): landed two half-iterations ago; split it into the other buffer, then reuse
+        // its registers for the loads of A(it+2)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("" : "+v"(u), "+v"(v));
+        split8_store(u, v, smem + ((it + 1) & 1) * BUF_BYTES + a_lds);
+        if (it + 2 < ktiles) LAB_LOAD_A(it + 2);
+      }
+      mma6(P, R, hi[0][1], lo[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(P, Q, hi[0][0], lo[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(S, Q, hi[1][0], lo[1][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(S, R, hi[1][1], lo[1][1]);
+    }
+#undef LAB_LOAD_A
+#undef LAB_STAGE_B
+    const int kh = lane >> 5, xl = lane & 31;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 32 + xl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * 64 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+          if (row < M && col < N) C[row * ldc + col] = hi[i][j][r] + lo[i][j][r];
+        }
+      }
+  }
+}
+
 int main(int argc, char **argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 51200, N = argc > 2 ? atoll(argv[2]) : 1024;
   const int64_t K = argc > 3 ? atoll(argv[3]) : 1024;
@@ -235,6 +387,26 @@ int main(int argc, char **argv) {
   run(gemm_planes_kernel<1, 2>, "128x128, 4 waves, persistent", 2, 1);
   run(gemm_planes_kernel<0, 4>, "128x256, 8 waves, one workgroup per tile", 4, 0);
   run(gemm_planes_kernel<1, 4>, "128x256, 8 waves, persistent", 4, 1);
+  {
+    const size_t lds = 2 * 3 * (size_t)OPERAND_BYTES;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int persist = 0; persist < 2; ++persist) {
+      const int grid = persist ? 256 : tiles_m * tiles_n / 2;
+      CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+      for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL(gemm_split_a_kernel, dim3(grid), dim3(512), lds, 0, dA, K, pB, dC, M, N, N, tiles_m, tiles_n, ktiles);
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipEventRecord(e0));
+      for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(gemm_split_a_kernel, dim3(grid), dim3(512), lds, 0, dA, K, pB, dC, M, N, N, tiles_m, tiles_n, ktiles);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+      printf("%-44s %lld x %lld x %lld  %.3f ms  %.1f TF (six-term work)\n",
+             persist ? "128x256, 8 waves split A themselves, persist." : "128x256, 8 waves split A themselves",
+             (long long)M, (long long)N, (long long)K, ms, 2.0 * M * N * K / ms / 1e9);
+    }
+  }
   // check a sample of entries against float64
   std::vector<float> hc((size_t)M * N);
   CHECK(hipMemcpy(hc.data(), dC, hc.size() * 4, hipMemcpyDeviceToHost));

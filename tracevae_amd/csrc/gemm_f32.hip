@@ -750,6 +750,316 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
   for (int q = 0; q < pend.left; ++q) store_piece(pend, q, staged_piece(ws, q, lane));
 }
 
+// ------------------------------------------------------------------------------------------
+// The wide form: the layer products that carry the time (many rows of a row-major A against a
+// small pre-split B: forward products and input gradients).
+//
+// 128 x 256 output tile, 512 threads = EIGHT waves that all multiply (2 x 4, a 64x64 block each,
+// the same 48 matrix instructions and 24 ds_read_b128 per k-tile as above), two per SIMD: while one
+// wave waits for its fragments or at the barrier the other keeps the matrix pipe busy.  B's two
+// plane images come global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write,
+// no vector ALU), A is split by the multiplying waves themselves between their matrix
+// instructions: 8 elements per thread and k-tile (two 16-byte loads, ~44 vector instructions,
+// three ds_write_b128).  Two LDS buffers of 72 KB, one barrier per k-tile, loads and DMAs counted
+// by hand (inline assembly: beside LDS-DMA in flight the compiler drains every load before a
+// ds_write of its own).  tools/gemm_planes_lab.hip measured the form first: 200 TF on
+// 51200 x 1024 x 1024 against 177 for four multiplying waves fed by four producer waves.
+// The output leaves straight from the accumulators (128-byte row segments per half-wave): no LDS
+// is left for a staged tile, and the two waves of a SIMD overlap each other's epilogue anyway.
+// Work units: output tiles, plus the tail split of the last partial round (packed 128x256 slabs,
+// gemm_wide_tail_reduce_kernel).
+constexpr int WBN = 256;
+constexpr int WIDE_BUF_BYTES = 3 * OPERAND_BYTES;      // A image | two B images
+
+__device__ __forceinline__ void wide_stage_b(const char *b_img, int64_t b_stride, char *buf, int wave, int lane) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  // 48 chunks of 1 KB over 8 waves: 3 per image and wave, lane-linear (the images are byte copies)
+  const unsigned voff = (unsigned)(wave * 3 * 1024 + lane * 16), loff = (unsigned)(wave * 3 * 1024);
+#pragma unroll
+  for (int img = 0; img < 2; ++img)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      __builtin_amdgcn_global_load_lds((const void *)(b_img + (int64_t)img * b_stride + voff + c * 1024),
+                                       (lds_void *)(buf + img * OPERAND_BYTES + loff + c * 1024), 16, 0, 0);
+}
+
+// three bf16 planes of 8 consecutive k of one row into the A image (stores the compiler does not
+// see, see above)
+__device__ __forceinline__ void wide_split_store(const f32x4 &u, const f32x4 &v, char *dst) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  unsigned pl[3][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 &x = h ? v : u;
+    const unsigned p01 = pack_bf16(x[0], x[1]), p23 = pack_bf16(x[2], x[3]);
+    const float e0 = x[0] - __uint_as_float(p01 << 16), e1 = x[1] - __uint_as_float(p01 & 0xffff0000u);
+    const float e2 = x[2] - __uint_as_float(p23 << 16), e3 = x[3] - __uint_as_float(p23 & 0xffff0000u);
+    const unsigned q01 = pack_bf16(e0, e1), q23 = pack_bf16(e2, e3);
+    const float f0 = e0 - __uint_as_float(q01 << 16), f1 = e1 - __uint_as_float(q01 & 0xffff0000u);
+    const float f2 = e2 - __uint_as_float(q23 << 16), f3 = e3 - __uint_as_float(q23 & 0xffff0000u);
+    pl[0][2 * h] = p01; pl[0][2 * h + 1] = p23;
+    pl[1][2 * h] = q01; pl[1][2 * h + 1] = q23;
+    pl[2][2 * h] = pack_bf16(f0, f1); pl[2][2 * h + 1] = pack_bf16(f2, f3);
+  }
+  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dst;
+  static_assert(PLANE_BYTES == 8192, "plane offsets below");
+  const u32x4 w0 = {pl[0][0], pl[0][1], pl[0][2], pl[0][3]};
+  const u32x4 w1 = {pl[1][0], pl[1][1], pl[1][2], pl[1][3]};
+  const u32x4 w2 = {pl[2][0], pl[2][1], pl[2][2], pl[2][3]};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w0) : "memory");
+  asm volatile("ds_write_b128 %0, %1 offset:8192" ::"v"(addr), "v"(w1) : "memory");
+  asm volatile("ds_write_b128 %0, %1 offset:16384" ::"v"(addr), "v"(w2) : "memory");
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs g) {
+  extern __shared__ __align__(16) char smem[];        // 2 x (A image | 2 B images)
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  constexpr int LA = ACT ? 6 : 2;                      // loads per thread and k-tile: A (+ coefficients)
+
+  // unit -> (tile, k-split); g.tiles_n counts 256-wide column tiles here
+  const int tail_units = g.tail_splits > 1;
+  const int nwg = tail_units ? (int)g.tail_first : (int)g.units;
+  const int u_id = blockIdx.x;
+  const bool tail = tail_units && u_id >= nwg;
+  int tile, sp = 0;
+  int64_t kchunk = g.K;
+  if (tail) {
+    const int v = u_id - nwg;
+    tile = nwg + v / (int)g.tail_splits;
+    sp = v % (int)g.tail_splits;
+    kchunk = g.tail_kchunk;
+  } else {
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xcd = u_id & 7, idx = u_id >> 3;
+    tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  tile = __builtin_amdgcn_readfirstlane(tile);
+  sp = __builtin_amdgcn_readfirstlane(sp);
+  const int tn = tile % (int)g.tiles_n, tm = tile / (int)g.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * WBN;
+  const int64_t kbeg = sp * kchunk;
+  const int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
+  const int64_t klen = kend - kbeg;
+  const int ntf = __builtin_amdgcn_readfirstlane((int)(klen / BK));
+  const int rem = __builtin_amdgcn_readfirstlane((int)(klen - (int64_t)ntf * BK));
+  const int nt = ntf + (rem ? 1 : 0);
+  // a partial last tile of at most 16 k holds nothing in its second k-step (K = 1000: 8 of 32)
+  const int nfull = (rem > 0 && rem <= 16) ? nt - 1 : nt;
+
+  // A: the thread owns row t>>2 of the tile, k = 8 (t&3) .. +7 of every k-tile
+  int64_t arow = t >> 2;
+  if (m0 + arow >= g.M) arow = g.M - 1 - m0;           // clamped rows only reach unstored accumulators
+  const int kq = 8 * (t & 3);
+  const unsigned a_off = (unsigned)((arow * g.lda + kq) * 4);
+  const unsigned a_lds = plane_offset(t >> 2, 2 * (t & 3));
+  const char *a_base = reinterpret_cast<const char *>(g.A + m0 * g.lda + kbeg);
+  const char *cs_base = reinterpret_cast<const char *>(g.act_scale + kbeg);
+  const char *ch_base = reinterpret_cast<const char *>(g.act_shift + kbeg);
+  const char *b_img = g.b_planes + ((int64_t)tn * 2 * g.b_ktiles + kbeg / BK) * OPERAND_BYTES;
+  const int64_t bs = g.b_ktiles * (int64_t)OPERAND_BYTES;
+
+  f32x4 u, v, su, sv, hu, hv;
+  // loads of k-tile KT: the same number for a full and for the partial tile (whose k beyond `rem`
+  // read the tile's first k instead and are zeroed once landed)
+  auto load_a = [&](int kt) {
+    const char *tp = a_base + (int64_t)kt * (BK * 4);
+    unsigned ou = a_off, ov = a_off + 16, cu = 4u * kq, cv = 4u * kq + 16;
+    if (kt >= ntf) {
+      if (kq >= rem) { ou = a_off - 4u * kq; cu = 0; }
+      if (kq + 4 >= rem) { ov = a_off - 4u * kq; cv = 0; }
+    }
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(u) : "v"(ou), "s"(tp));
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(ov), "s"(tp));
+    if constexpr (ACT) {
+      const char *sp_ = cs_base + (int64_t)kt * (BK * 4), *hp_ = ch_base + (int64_t)kt * (BK * 4);
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(su) : "v"(cu), "s"(sp_));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sv) : "v"(cv), "s"(sp_));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hu) : "v"(cu), "s"(hp_));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hv) : "v"(cv), "s"(hp_));
+    }
+  };
+  // landed tile KT: prologue, zero fill of a partial tile, split, planes into buffer KT & 1
+  auto split_a = [&](int kt) {
+    if constexpr (ACT) asm volatile("" : "+v"(u), "+v"(v), "+v"(su), "+v"(sv), "+v"(hu), "+v"(hv));
+    else asm volatile("" : "+v"(u), "+v"(v));
+    if constexpr (ACT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = u[j] * su[j] + hu[j], b = v[j] * sv[j] + hv[j];
+        u[j] = fmaxf(a, a * g.act_slope);
+        v[j] = fmaxf(b, b * g.act_slope);
+      }
+    }
+    if (kt >= ntf) {
+      if (kq >= rem) u = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kq + 4 >= rem) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    wide_split_store(u, v, smem + (kt & 1) * WIDE_BUF_BYTES + a_lds);
+  };
+
+  f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+
+  wide_stage_b(b_img, bs, smem + OPERAND_BYTES, wave, lane);
+  load_a(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  split_a(0);
+  if (nt > 1) load_a(1);
+
+  for (int it = 0; it < nfull; ++it) {
+    const bool more = it + 1 < nt;
+    // B(it) has landed (the loads of A(it+1) may still fly); this wave's plane stores are done
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // ... of every wave; the other buffer is free
+    asm volatile("" ::: "memory");
+    if (more)
+      wide_stage_b(b_img + (int64_t)(it + 1) * OPERAND_BYTES, bs,
+                   smem + ((it + 1) & 1) * WIDE_BUF_BYTES + OPERAND_BYTES, wave, lane);
+    const char *As = smem + (it & 1) * WIDE_BUF_BYTES;
+    const char *Bs = As + OPERAND_BYTES + (wn >> 1) * OPERAND_BYTES;
+    const int bn0 = (wn & 1) * 64;
+    bf16x8 P[3], Q[3], R[3], S[3];
+    read_set(As, wm * 64, lane, 0, P);
+    read_set(Bs, bn0, lane, 0, Q);
+    read_set(Bs, bn0 + 32, lane, 0, R);
+    read_set(As, wm * 64 + 32, lane, 0, S);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(P, Q, hi[0][0], lo[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(P, R, hi[0][1], lo[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(As, wm * 64, lane, 1, P);
+    mma6(S, R, hi[1][1], lo[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(Bs, bn0 + 32, lane, 1, R);
+    mma6(S, Q, hi[1][0], lo[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(Bs, bn0, lane, 1, Q);
+    read_set(As, wm * 64 + 32, lane, 1, S);
+    if (more) {
+      // A(it+1) landed long ago (only this iteration's six DMAs are younger): split it into the
+      // other buffer, then its registers take the loads of A(it+2)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      split_a(it + 1);
+      if (it + 2 < nt) load_a(it + 2);
+    }
+    mma6(P, R, hi[0][1], lo[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(P, Q, hi[0][0], lo[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(S, Q, hi[1][0], lo[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(S, R, hi[1][1], lo[1][1]);
+  }
+  if (nfull < nt) {                                    // the short last tile: first k-step only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char *As = smem + (nfull & 1) * WIDE_BUF_BYTES;
+    const char *Bs = As + OPERAND_BYTES + (wn >> 1) * OPERAND_BYTES;
+    const int bn0 = (wn & 1) * 64;
+    bf16x8 P[3], Q[3], R[3], S[3];
+    read_set(As, wm * 64, lane, 0, P);
+    read_set(Bs, bn0, lane, 0, Q);
+    read_set(Bs, bn0 + 32, lane, 0, R);
+    read_set(As, wm * 64 + 32, lane, 0, S);
+    mma6(P, Q, hi[0][0], lo[0][0]);
+    mma6(P, R, hi[0][1], lo[0][1]);
+    mma6(S, R, hi[1][1], lo[1][1]);
+    mma6(S, Q, hi[1][0], lo[1][0]);
+  }
+
+  // epilogue, straight from the accumulators.  C/D layout of the 32x32 MFMA: col = lane & 31,
+  // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  const int kh = lane >> 5, xl = lane & 31;
+  if (tail) {
+    float *slab = g.tail_slabs + ((int64_t)(tile - nwg) * g.tail_splits + sp) * (BM * WBN);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[(wm * 64 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * WBN + wn * 64 + j * 32 + xl] =
+              hi[i][j][r] + lo[i][j][r];
+    return;
+  }
+  // (the bias values are waited for ONCE, here: a compiler-counted load would be waited for with
+  // vmcnt(0) before every store that uses it, which also waits for the store before it)
+  const int64_t col0 = n0 + wn * 64 + xl;
+  float bv0 = (g.bias && col0 < g.N) ? g.bias[col0] : 0.f;
+  float bv1 = (g.bias && col0 + 32 < g.N) ? g.bias[col0 + 32] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1)::"memory");
+  float *o = g.C + (m0 + wm * 64 + 4 * kh) * g.ldc + col0;
+  if (m0 + BM <= g.M) {
+    // all 128 rows exist: stores are only predicated on the column of the lane
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (col0 + j * 32 < g.N) {
+        const float bv = j ? bv1 : bv0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            o[(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32] = hi[i][j][r] + lo[i][j][r] + bv;
+      }
+    }
+    return;
+  }
+  const int64_t rbase = m0 + wm * 64 + 4 * kh;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bool colok = col0 + j * 32 < g.N;
+    const float bv = j ? bv1 : bv0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (colok && rbase + rr < g.M) o[rr * g.ldc + j * 32] = hi[i][j][r] + lo[i][j][r] + bv;
+      }
+  }
+}
+
+// second stage of the wide form's tail split: C tile = sum_s slab[tile][s] + bias in split order.
+// One workgroup per 16 rows of a tail tile; a thread owns 4 consecutive columns of 4 rows.
+__global__ __launch_bounds__(256) void gemm_wide_tail_reduce_kernel(GemmArgs g) {
+  const int64_t rel = blockIdx.x >> 3;
+  const int64_t tile = g.tail_first + rel;
+  const int64_t tn = tile % g.tiles_n, tm = tile / g.tiles_n;
+  const int t = threadIdx.x;
+  const int c4 = (t & 63) * 4;
+  const float *slab = g.tail_slabs + rel * g.tail_splits * (BM * WBN);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = (blockIdx.x & 7) * 16 + (t >> 6) + 4 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t s = 0; s < g.tail_splits; ++s) {
+      const float4 p = *reinterpret_cast<const float4 *>(&slab[s * (BM * WBN) + rl * WBN + c4]);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const int64_t row = tm * BM + rl;
+    if (row >= g.M) continue;
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t col = tn * WBN + c4 + j;
+      if (col < g.N) g.C[row * g.ldc + col] = e[j] + (g.bias ? g.bias[col] : 0.f);
+    }
+  }
+}
+
 // second stage of split-K: out = epilogue(sum_s slab[s]) in slab order
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   const int64_t total = g.M * g.N;
@@ -820,6 +1130,10 @@ struct Plan {
   int64_t slab_bytes;                               // slabs of either split, at the workspace's start
   int64_t planes_bytes;                             // pre-split B behind them (0: split in the kernel)
   int64_t workspace_bytes;
+  // the wide form (128 x 256 tiles, gemm_wide_kernel): taken when the shape allows it and the
+  // operands qualify (run_gemm); its tail split has slabs of its own size
+  bool wide;
+  int64_t w_tiles, w_tail_first, w_tail_splits, w_tail_kchunk, w_slab_bytes;
 };
 
 int64_t choose_splits(int64_t m, int64_t n, int64_t k);
@@ -853,8 +1167,31 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
   // B is split ahead of the product when it is small and every piece of it is needed by many
   // row tiles (a layer's weights under >= 2048 rows): 6 bytes per element of scratch
   p.planes_bytes = 0;
+  // (an even number of 128-column images: the wide form takes them two at a time)
   if (m >= 2048 && n * k <= (1ll << 22))
-    p.planes_bytes = tv_cdiv(n, BN) * tv_cdiv(k, BK) * (int64_t)OPERAND_BYTES;
+    p.planes_bytes = ((tv_cdiv(n, BN) + 1) & ~1ll) * tv_cdiv(k, BK) * (int64_t)OPERAND_BYTES;
+  // the wide form: enough 128 x 256 tiles for two rounds of the chip, B pre-split, no split-K
+  p.w_tiles = tv_cdiv(m, BM) * tv_cdiv(n, WBN);
+  p.wide = p.planes_bytes > 0 && p.splits == 1 && p.w_tiles >= 2 * slots && p.w_tiles < (1ll << 30);
+  p.w_tail_first = p.w_tiles; p.w_tail_splits = 1; p.w_tail_kchunk = tv_cdiv(k, BK) * BK; p.w_slab_bytes = 0;
+  if (p.wide) {
+    const int64_t tail = p.w_tiles % slots;
+    if (tail > 0) {
+      int64_t ts = slots / tail;
+      const int64_t kmax = k / (4 * BK);
+      if (ts > kmax) ts = kmax;
+      if (ts > 8) ts = 8;
+      if (ts >= 2) {
+        const int64_t kc = tv_cdiv(tv_cdiv(k, ts), BK) * BK;
+        ts = tv_cdiv(k, kc);
+        if (ts >= 2) {
+          p.w_tail_first = p.w_tiles - tail; p.w_tail_splits = ts; p.w_tail_kchunk = kc;
+          p.w_slab_bytes = tail * ts * (int64_t)(BM * WBN * sizeof(float));
+        }
+      }
+    }
+  }
+  if (p.w_slab_bytes > p.slab_bytes) p.slab_bytes = p.w_slab_bytes;   // either form may be taken
   p.slab_bytes = (p.slab_bytes + 255) & ~255ll;
   p.workspace_bytes = p.slab_bytes + p.planes_bytes;
   return p;
@@ -945,9 +1282,43 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gemm_f32: workspace must be 16-byte aligned");
     char *planes = (char *)workspace + plan.slab_bytes;
     g.b_planes = planes;
-    hipLaunchKernelGGL(gemm_split_b_kernel, dim3((unsigned)(g.tiles_n * g.b_ktiles)), dim3(256), 0, s,
-                       b, ldb, trans_b ? 0 : 1, n, k, g.b_ktiles, planes);
+    hipLaunchKernelGGL(gemm_split_b_kernel, dim3((unsigned)(((g.tiles_n + 1) & ~1ll) * g.b_ktiles)),
+                       dim3(256), 0, s, b, ldb, trans_b ? 0 : 1, n, k, g.b_ktiles, planes);
     TV_LAUNCH_CHECK("tv_gemm_f32(split of B)");
+  }
+  // the wide form: a row-major A that can be read 16 bytes at a time against the pre-split B,
+  // plain epilogue (bias at most)
+  if (plan.wide && presplit && !trans_a && g.a_vec && !row_scale && !accumulate && act_operand != 2) {
+    GemmArgs w = g;
+    w.tiles_n = tv_cdiv(n, WBN);
+    w.tail_first = plan.w_tail_first; w.tail_splits = plan.w_tail_splits; w.tail_kchunk = plan.w_tail_kchunk;
+    w.tail_slabs = plan.w_tail_splits > 1 ? (float *)workspace : nullptr;
+    const int64_t units = plan.w_tail_splits > 1
+                              ? plan.w_tail_first + (plan.w_tiles - plan.w_tail_first) * plan.w_tail_splits
+                              : plan.w_tiles;
+    TV_REQUIRE(units < (1ll << 31), "tv_gemm_f32: grid too large");
+    w.units = units;
+    const size_t wlds = 2 * (size_t)WIDE_BUF_BYTES;
+    int device = 0;
+    TV_HIP(hipGetDevice(&device));
+    static bool raised[2][64] = {};
+    const int wa = act_operand == 1;
+    if (!raised[wa][device & 63]) {
+      if (wa) TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+      else TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+      raised[wa][device & 63] = true;
+    }
+    if (wa) hipLaunchKernelGGL(gemm_wide_kernel<true>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    else hipLaunchKernelGGL(gemm_wide_kernel<false>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    TV_LAUNCH_CHECK("tv_gemm_f32(wide)");
+    if (w.tail_splits > 1) {
+      hipLaunchKernelGGL(gemm_wide_tail_reduce_kernel, dim3((unsigned)((plan.w_tiles - w.tail_first) * 8)),
+                         dim3(256), 0, s, w);
+      TV_LAUNCH_CHECK("tv_gemm_f32(wide tail reduce)");
+    }
+    return TV_OK;
   }
   const int64_t tiles = g.tiles_m * g.tiles_n;
   const int64_t nwg = g.tail_splits > 1 ? g.tail_first + (tiles - g.tail_first) * g.tail_splits
