@@ -49,7 +49,7 @@ def per_kernel(path, counter):
     return out
 
 
-def traffic(fetch_csv, write_csv, dst, family='gemm_kernel'):
+def traffic(fetch_csv, write_csv, dst, family=('gemm_kernel', 'gemm_wide_kernel')):
     f = per_kernel(fetch_csv, 'FETCH_SIZE')
     w = per_kernel(write_csv, 'WRITE_SIZE')
     kernels = {}
@@ -66,7 +66,7 @@ def traffic(fetch_csv, write_csv, dst, family='gemm_kernel'):
             fam[2] += wkib * 1024.0
     doc = {'note': 'FETCH_SIZE (KiB, x2 gfx950 correction) + WRITE_SIZE (KiB) from separate --pmc '
                    'passes; L2 fabric-side requests, Infinity-Cache hits included',
-           'family': family, 'family_launches': fam[0],
+           'family': ' / '.join(family), 'family_launches': fam[0],
            'family_bytes_per_launch': (fam[1] + fam[2]) / max(fam[0], 1),
            'family_read_bytes_per_launch': fam[1] / max(fam[0], 1),
            'family_write_bytes_per_launch': fam[2] / max(fam[0], 1),

@@ -1001,6 +1001,37 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs g) {
   float bv0 = (g.bias && col0 < g.N) ? g.bias[col0] : 0.f;
   float bv1 = (g.bias && col0 + 32 < g.N) ? g.bias[col0 + 32] : 0.f;
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1)::"memory");
+  if (g.c_vec && m0 + BM <= g.M) {
+    // all 128 rows exist and rows can be written 16 bytes per lane: the wave transposes its
+    // block, 32 rows at a time, through 8 KB of the LDS buffer that the last k-tile did not use
+    // (free since the barrier before it; the region is this wave's alone and a wave's LDS
+    // accesses execute in order) and stores 256-byte row segments, non-temporal.  Dword stores
+    // from the accumulator layout wrote 128-byte segments at 4016-byte row strides: 40 % more
+    // bytes at the memory than the tile holds.
+    float *ws = reinterpret_cast<float *>(smem + (nt & 1) * WIDE_BUF_BYTES) + wave * (32 * 64);
+    const int c = (lane & 15) * 4;
+    const int64_t col = n0 + wn * 64 + c;
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && col < g.N) bq = *reinterpret_cast<const f32x4 *>(g.bias + col);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq)::"memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ws[(4 * kh + (r & 3) + 8 * (r >> 2)) * 64 + ((j * 32 + xl) ^ (kh << 5))] = hi[i][j][r] + lo[i][j][r];
+      if (col < g.N) {                               // N % 4 == 0: the four columns exist together
+        float *orow = g.C + (m0 + wm * 64 + i * 32 + (lane >> 4)) * g.ldc + col;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 x = *reinterpret_cast<const f32x4 *>(&ws[(q * 4 + (lane >> 4)) * 64 + (c ^ ((q & 1) << 5))]);
+          __builtin_nontemporal_store(x + bq, reinterpret_cast<f32x4 *>(orow + (int64_t)q * 4 * g.ldc));
+        }
+      }
+    }
+    return;
+  }
   float *o = g.C + (m0 + wm * 64 + 4 * kh) * g.ldc + col0;
   if (m0 + BM <= g.M) {
     // all 128 rows exist: stores are only predicated on the column of the lane
