@@ -934,6 +934,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs g) {
     read_set(Bs, bn0 + 32, lane, 0, R);
     read_set(As, wm * 64 + 32, lane, 0, S);
     __builtin_amdgcn_sched_barrier(0);
+    // the first half of a k-tile's matrix instructions runs at raised priority, the split and the
+    // second half at normal priority: the two waves of a SIMD then fall half a k-tile out of
+    // step and fill each other's gaps (+4 % on the layer products; raising both halves, or
+    // only the first two groups, loses it again)
+    __builtin_amdgcn_s_setprio(1);
     mma6(P, Q, hi[0][0], lo[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     mma6(P, R, hi[0][1], lo[0][1]);
@@ -946,6 +951,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
     read_set(Bs, bn0, lane, 1, Q);
     read_set(As, wm * 64 + 32, lane, 1, S);
+    __builtin_amdgcn_s_setprio(0);
     if (more) {
       // A(it+1) landed long ago (only this iteration's six DMAs are younger): split it into the
       // other buffer, then its registers take the loads of A(it+2)
