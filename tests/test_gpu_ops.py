@@ -67,6 +67,44 @@ def test_gemm_many_units_per_workgroup(device, m, n, k, ta, tb, strided):
     assert torch.equal(got, ops.gemm(a, b, ta, tb, bias=bias))      # bit-stable
 
 
+@pytest.mark.parametrize('m,n,k,act,strided', [
+    (1000, 1000, 5017, False, False),   # partial last k-tile in the last split, edge tiles both ways
+    (1000, 1000, 5017, True, False),    # ... with the BatchNorm + LeakyReLU prologue on B
+    (1004, 500, 3000, True, True),      # fc product with score columns; operands are column views
+    (128, 260, 777, False, False),      # second column tile holds 4 columns
+    (300, 132, 257, True, False),       # a split of one full k-tile and one row
+    (1000, 1000, 130, False, False),    # k too short for two splits of two k-tiles: the other kernel
+    (64, 1000, 4096, True, False),      # one row tile
+    (1000, 1000, 51200, True, False),   # the weight gradient of the bench's layers
+])
+def test_gemm_kmajor_operands_wide_form(device, m, n, k, act, strided):
+    """Weight gradients C = A^T B with both operands k-major go through gemm_kmajor_wide_kernel
+    (planes k-major in LDS, transposing fragment reads, packed split-K slabs) when M, N are
+    multiples of 4 and the tiles fit one round of the chip; against the float64 product."""
+    from tracevae_amd import ops
+    gen = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    if strided:
+        a = torch.randn(k, m + 8, generator=gen).to(device)[:, 4:m + 4]
+        b = torch.randn(k, n + 12, generator=gen).to(device)[:, 8:n + 8]
+    else:
+        a = torch.randn(k, m, generator=gen).to(device)
+        b = torch.randn(k, n, generator=gen).to(device)
+    bias = torch.randn(n, generator=gen).to(device)
+    Bm = b.double()
+    kw = {}
+    if act:
+        scale = (0.5 + torch.rand(n, generator=gen)).to(device)
+        shift = (0.3 * torch.randn(n, generator=gen)).to(device)
+        kw['act'] = (2, scale, shift, 0.01)
+        Bm = F.leaky_relu(Bm * scale.double() + shift.double(), 0.01)
+    want = a.double().t() @ Bm + bias.double()
+    wide = torch.full([m, n + 4], float('nan'), device=device)
+    got = ops.gemm(a, b, True, False, bias=bias, out=wide[:, :n], **kw)
+    assert torch.isnan(wide[:, n:]).all()
+    assert rel_err(got, want) < 2e-5
+    assert torch.equal(got, ops.gemm(a, b, True, False, bias=bias, **kw))       # bit-stable
+
+
 def test_gemm_split_k_and_accumulate(device):
     from tracevae_amd import ops
     # weight-gradient shape: small output, long reduction -> split-K path

@@ -1097,6 +1097,236 @@ __global__ __launch_bounds__(256) void gemm_wide_tail_reduce_kernel(GemmArgs g) 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The wide form for k-major operands: the weight gradients, C[M,N] = A^T B with A = [K][M] (a
+// layer's output gradient) and B = [K][N] (its input, optionally behind the deferred
+// BatchNorm + LeakyReLU prologue), K = graph nodes of the batch, M and N = layer widths.
+//
+// Same shape as gemm_wide_kernel (128 x 256 tile, eight multiplying waves, two 72 KB buffers, one
+// barrier per k-tile), but a thread that loads 16 bytes of such an operand holds ONE k of four x
+// where a matrix-instruction operand wants eight k of one x.  The planes therefore stay k-major
+// in LDS ([k][x] bf16 rows of 256 bytes, the 16-byte chunk index XOR-ed with the row: the
+// dual-use image of the MI355X guide), a thread stores its four bf16 of a plane with one
+// ds_write_b64, and the fragments come out through the transposing read of gfx950
+// (ds_read_b64_tr_b16: a 4-row x 16-column block per 16 lanes, delivered column-major; two of
+// them make the eight k of a lane).  Per thread and k-tile: six 16-byte loads (two of A, four of
+// B) where the producer / consumer kernel needs 32 4-byte loads per producer thread; each float4
+// is split after one of the six first blocks of matrix instructions of the tile before, so that
+// its ~26 vector instructions issue between the dependent matrix instructions of the block, and
+// its registers take the load of the tile after next at once (one register set, the count of
+// loads in flight is the same at every wait: 5 younger ones).
+// tools/gemm_kmajor_lab.hip measured the form first: 196 TF on 1024 x 1024 x 51200 in 256 units
+// against 163-167 for the producer / consumer kernel on the same product.
+// Work units: (tile, k-split) pairs, one round of the chip, k-split fastest so that the units of
+// one k-range (which share its rows of A and B) run on one XCD; packed 128 x 256 slabs, summed in
+// split order by gemm_wide_tail_reduce_kernel.  M % 4 == N % 4 == 0 (a float4 of an operand row is
+// inside or outside as a whole; outside ones read column 0 of the tile and only reach unstored
+// accumulators).  The rows of a partial last k-tile are multiplied after the pipelined loop, in
+// a step of their own whose loads are clamped to row K - 1 and whose A elements beyond K are zero.
+__device__ __forceinline__ unsigned kmajor_offset(int k, int ch) {   // 16-byte chunk ch of row k
+  return (unsigned)(256 * k + 16 * (ch ^ (((k & 3) << 2) | ((k >> 2) & 3))));
+}
+
+// four x of one k -> 8 bytes in each of the three planes of a k-major image
+__device__ __forceinline__ void kmajor_split_store(const f32x4 &x, char *dst) {
+  const unsigned p01 = pack_bf16(x[0], x[1]), p23 = pack_bf16(x[2], x[3]);
+  const float e0 = x[0] - __uint_as_float(p01 << 16), e1 = x[1] - __uint_as_float(p01 & 0xffff0000u);
+  const float e2 = x[2] - __uint_as_float(p23 << 16), e3 = x[3] - __uint_as_float(p23 & 0xffff0000u);
+  const unsigned q01 = pack_bf16(e0, e1), q23 = pack_bf16(e2, e3);
+  const float f0 = e0 - __uint_as_float(q01 << 16), f1 = e1 - __uint_as_float(q01 & 0xffff0000u);
+  const float f2 = e2 - __uint_as_float(q23 << 16), f3 = e3 - __uint_as_float(q23 & 0xffff0000u);
+  *reinterpret_cast<uint2 *>(dst) = make_uint2(p01, p23);
+  *reinterpret_cast<uint2 *>(dst + PLANE_BYTES) = make_uint2(q01, q23);
+  *reinterpret_cast<uint2 *>(dst + 2 * PLANE_BYTES) = make_uint2(pack_bf16(f0, f1), pack_bf16(f2, f3));
+}
+
+// the three planes of a 32-x sub-tile for one 16-deep k-step, transposed on the way out of LDS:
+// lane l gets x = xbase + (l & 31), k = 16 step + 8 (l >> 5) .. +7
+__device__ __forceinline__ void read_set_tr(const char *img, int xbase, int lane, int step, bf16x8 (&f)[3]) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int gq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int ch = ((xbase + 16 * (gq & 1)) >> 3) + (p >> 1);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    s16x4 h[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int row = 16 * step + 8 * (gq >> 1) + 4 * hh + q;
+      const char *a = img + pl * PLANE_BYTES + kmajor_offset(row, ch) + 8 * (p & 1);
+      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)a);
+    }
+    const s16x8 v = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+    f[pl] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(512) void gemm_kmajor_wide_kernel(GemmArgs g) {
+  extern __shared__ __align__(16) char smem[];        // 2 x (A image | 2 B images), k-major
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nsp = (int)g.tail_splits;
+  const int sp = __builtin_amdgcn_readfirstlane((int)blockIdx.x % nsp);
+  const int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x / nsp);
+  const int tn = tile % (int)g.tiles_n, tm = tile / (int)g.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * WBN;
+  const int64_t kbeg = sp * g.tail_kchunk;
+  const int64_t kend = (kbeg + g.tail_kchunk < g.K) ? (kbeg + g.tail_kchunk) : g.K;
+  const int ntf = __builtin_amdgcn_readfirstlane((int)((kend - kbeg) / BK));
+  const int rem = __builtin_amdgcn_readfirstlane((int)(kend - kbeg - (int64_t)ntf * BK));
+
+  // A: the thread owns x = 4 (t & 31) .. +3 of rows k = t >> 5 and 16 + (t >> 5) of every k-tile
+  // B: x = 4 (t & 63) .. +3 of rows k = (t >> 6) + 8 j, j = 0..3
+  const int ax = 4 * (t & 31), ak = t >> 5;
+  const int bx = 4 * (t & 63), bk = t >> 6;
+  const int axc = (m0 + ax < g.M) ? ax : 0, bxc = (n0 + bx < g.N) ? bx : 0;
+  const char *a_base = reinterpret_cast<const char *>(g.A + kbeg * g.lda + m0);
+  const char *b_base = reinterpret_cast<const char *>(g.B + kbeg * g.ldb + n0);
+  auto krow = [&](int j) { return j < 2 ? ak + 16 * j : bk + 8 * (j - 2); };
+  unsigned off[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    off[j] = j < 2 ? (unsigned)((krow(j) * g.lda + axc) * 4) : (unsigned)((krow(j) * g.ldb + bxc) * 4);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (ACT) {
+    sc = *reinterpret_cast<const f32x4 *>(g.act_scale + n0 + bxc);
+    sh = *reinterpret_cast<const f32x4 *>(g.act_shift + n0 + bxc);
+  }
+  f32x4 r[6];
+  auto tile_a = [&](int kt) { return a_base + (int64_t)kt * BK * g.lda * 4; };
+  auto tile_b = [&](int kt) { return b_base + (int64_t)kt * BK * g.ldb * 4; };
+  // piece j of a landed tile: prologue (B), split, planes into buffer `buf`
+  auto split_piece = [&](int j, char *buf) {
+    if (j < 2) {
+      kmajor_split_store(r[j], buf + kmajor_offset(krow(j), ax >> 3) + 2 * (ax & 7));
+    } else {
+      f32x4 v = r[j];
+      if constexpr (ACT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = v[e] * sc[e] + sh[e];
+          v[e] = fmaxf(a, a * g.act_slope);
+        }
+      }
+      kmajor_split_store(v, buf + OPERAND_BYTES + (bx >> 7) * OPERAND_BYTES +
+                                kmajor_offset(krow(j), (bx & 127) >> 3) + 2 * (bx & 7));
+    }
+  };
+
+  f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { hi[i][j][q] = 0.f; lo[i][j][q] = 0.f; }
+
+  // one k-tile out of buffer `As`; piece(j) runs after the j-th block of matrix instructions
+  auto multiply = [&](const char *As, auto &&piece) {
+    const char *Bs = As + OPERAND_BYTES + (wn >> 1) * OPERAND_BYTES;
+    const int bn0 = (wn & 1) * 64;
+    bf16x8 P[3], Q[3], R[3], S[3];
+    read_set_tr(As, wm * 64, lane, 0, P);
+    read_set_tr(Bs, bn0, lane, 0, Q);
+    read_set_tr(Bs, bn0 + 32, lane, 0, R);
+    read_set_tr(As, wm * 64 + 32, lane, 0, S);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mma6(P, Q, hi[0][0], lo[0][0]);
+    piece(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(P, R, hi[0][1], lo[0][1]);
+    piece(1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_tr(As, wm * 64, lane, 1, P);
+    mma6(S, R, hi[1][1], lo[1][1]);
+    piece(2);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_tr(Bs, bn0 + 32, lane, 1, R);
+    mma6(S, Q, hi[1][0], lo[1][0]);
+    piece(3);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_tr(Bs, bn0, lane, 1, Q);
+    read_set_tr(As, wm * 64 + 32, lane, 1, S);
+    __builtin_amdgcn_s_setprio(0);
+    mma6(P, R, hi[0][1], lo[0][1]);
+    piece(4);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(P, Q, hi[0][0], lo[0][0]);
+    piece(5);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(S, Q, hi[1][0], lo[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma6(S, R, hi[1][1], lo[1][1]);
+  };
+  auto nothing = [](int) {};
+
+  if (ntf > 0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? tile_a(0) : tile_b(0)));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5])::"memory");
+#pragma unroll
+    for (int j = 0; j < 6; ++j) split_piece(j, smem);
+    const int t1 = ntf > 1 ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? tile_a(t1) : tile_b(t1)));
+    for (int it = 0; it + 1 < ntf; ++it) {
+      __syncthreads();                                 // the planes of tile it are in buffer it & 1
+      char *other = smem + ((it + 1) & 1) * WIDE_BUF_BYTES;
+      const int kt = it + 2 < ntf ? it + 2 : ntf - 1;  // (the last reload is a repeat, never used)
+      const char *ta = tile_a(kt), *tb = tile_b(kt);
+      multiply(smem + (it & 1) * WIDE_BUF_BYTES, [&](int j) {
+        asm volatile("s_waitcnt vmcnt(5)" : "+v"(r[j]));
+        split_piece(j, other);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? ta : tb));
+      });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (rem > 0) {
+    // the partial k-tile: loads in flight across the last full tile's matrix instructions
+    const char *ta = tile_a(ntf), *tb = tile_b(ntf);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int kr = krow(j) < rem ? krow(j) : rem - 1;
+      const unsigned o = j < 2 ? (unsigned)((kr * g.lda + axc) * 4) : (unsigned)((kr * g.ldb + bxc) * 4);
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(o), "s"(j < 2 ? ta : tb));
+    }
+  }
+  if (ntf > 0) {
+    __syncthreads();
+    multiply(smem + ((ntf - 1) & 1) * WIDE_BUF_BYTES, nothing);
+  }
+  if (rem > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5])::"memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (krow(j) >= rem) r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    char *buf = smem + (ntf & 1) * WIDE_BUF_BYTES;    // last read two barriers ago
+#pragma unroll
+    for (int j = 0; j < 6; ++j) split_piece(j, buf);
+    __syncthreads();
+    multiply(buf, nothing);
+  }
+
+  // packed slab of the unit, straight from the accumulators: 128-byte segments of 1 KB rows
+  const int kh = lane >> 5, xl = lane & 31;
+  float *slab = g.tail_slabs + ((int64_t)tile * nsp + sp) * (BM * WBN);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        slab[(wm * 64 + i * 32 + 4 * kh + (q & 3) + 8 * (q >> 2)) * WBN + wn * 64 + j * 32 + xl] =
+            hi[i][j][q] + lo[i][j][q];
+}
+
 // second stage of split-K: out = epilogue(sum_s slab[s]) in slab order
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   const int64_t total = g.M * g.N;
@@ -1171,6 +1401,9 @@ struct Plan {
   // operands qualify (run_gemm); its tail split has slabs of its own size
   bool wide;
   int64_t w_tiles, w_tail_first, w_tail_splits, w_tail_kchunk, w_slab_bytes;
+  // the wide form for k-major operands (gemm_kmajor_wide_kernel): every tile split over K into
+  // one round of the chip; 0 splits = not taken
+  int64_t km_splits, km_kchunk, km_slab_bytes;
 };
 
 int64_t choose_splits(int64_t m, int64_t n, int64_t k);
@@ -1229,6 +1462,20 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
     }
   }
   if (p.w_slab_bytes > p.slab_bytes) p.slab_bytes = p.w_slab_bytes;   // either form may be taken
+  p.km_splits = 0; p.km_kchunk = 0; p.km_slab_bytes = 0;
+  if (p.splits > 1 && p.planes_bytes == 0 && n > BN && 2 * p.w_tiles <= slots) {
+    int64_t ks = slots / p.w_tiles;                   // floor: never a second, partial round
+    const int64_t kmax = k / (2 * BK);
+    if (ks > kmax) ks = kmax;
+    if (ks > 64) ks = 64;
+    if (ks >= 2) {
+      p.km_kchunk = tv_cdiv(tv_cdiv(k, ks), BK) * BK;
+      p.km_splits = tv_cdiv(k, p.km_kchunk);
+      p.km_slab_bytes = p.w_tiles * p.km_splits * (int64_t)(BM * WBN * sizeof(float));
+      if (p.km_splits < 2) { p.km_splits = 0; p.km_slab_bytes = 0; }
+    }
+  }
+  if (p.km_slab_bytes > p.slab_bytes) p.slab_bytes = p.km_slab_bytes;
   p.slab_bytes = (p.slab_bytes + 255) & ~255ll;
   p.workspace_bytes = p.slab_bytes + p.planes_bytes;
   return p;
@@ -1355,6 +1602,37 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
                          dim3(256), 0, s, w);
       TV_LAUNCH_CHECK("tv_gemm_f32(wide tail reduce)");
     }
+    return TV_OK;
+  }
+  // the wide form for k-major operands (weight gradients): both operands readable 16 bytes at a
+  // time along x, plain epilogue (bias at most), B prologue allowed
+  if (plan.km_splits > 1 && trans_a && !trans_b && g.a_vec && g.b_vec && !presplit && !row_scale &&
+      !accumulate && act_operand != 1) {
+    TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gemm_f32: workspace must be 16-byte aligned");
+    GemmArgs w = g;
+    w.tiles_n = tv_cdiv(n, WBN);
+    w.splits = 1; w.slabs = nullptr;
+    w.tail_first = 0; w.tail_splits = plan.km_splits; w.tail_kchunk = plan.km_kchunk;
+    w.tail_slabs = (float *)workspace;
+    const int64_t units = plan.w_tiles * plan.km_splits;
+    w.units = units;
+    const size_t wlds = 2 * (size_t)WIDE_BUF_BYTES;
+    int device = 0;
+    TV_HIP(hipGetDevice(&device));
+    static bool raised[2][64] = {};
+    const int wa = act_operand == 2;
+    if (!raised[wa][device & 63]) {
+      if (wa) TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kmajor_wide_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+      else TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kmajor_wide_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+      raised[wa][device & 63] = true;
+    }
+    if (wa) hipLaunchKernelGGL(gemm_kmajor_wide_kernel<true>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    else hipLaunchKernelGGL(gemm_kmajor_wide_kernel<false>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    TV_LAUNCH_CHECK("tv_gemm_f32(k-major wide)");
+    hipLaunchKernelGGL(gemm_wide_tail_reduce_kernel, dim3((unsigned)(plan.w_tiles * 8)), dim3(256), 0, s, w);
+    TV_LAUNCH_CHECK("tv_gemm_f32(k-major wide reduce)");
     return TV_OK;
   }
   const int64_t tiles = g.tiles_m * g.tiles_n;
