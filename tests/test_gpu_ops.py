@@ -75,6 +75,7 @@ def test_gemm_many_units_per_workgroup(device, m, n, k, ta, tb, strided):
     (300, 132, 257, True, False),       # a split of one full k-tile and one row
     (1000, 1000, 130, False, False),    # k too short for two splits of two k-tiles: the other kernel
     (64, 1000, 4096, True, False),      # one row tile
+    (1000, 2304, 200, False, False),    # 72 tiles x 3 splits of 96, 96 and 8 rows: a unit with no full k-tile
     (1000, 1000, 51200, True, False),   # the weight gradient of the bench's layers
 ])
 def test_gemm_kmajor_operands_wide_form(device, m, n, k, act, strided):
