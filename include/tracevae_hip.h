@@ -155,7 +155,10 @@ int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int64_t num_ed
  * many shapes), used for the split-K slabs of weight-gradient shapes, for the K-split of the
  * output tiles of a partial last round of workgroups (both summed in a fixed order by a second
  * kernel), and for the bf16 pieces of a small B that is split once per call (m >= 2048,
- * n * k <= 2^22: 6 bytes per padded element).
+ * n * k <= 2^25: 6 bytes per padded element, at most ~200 MB).
+ * A row-major A whose k is not a multiple of 4 is still read 16 bytes at a time when lda is a
+ * multiple of 4, lda >= k rounded up to 4 and a is 16-byte aligned (the floats between k and
+ * the rounded k must be readable; their values do not matter).
  * ---------------------------------------------------------------------------------- */
 int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
@@ -404,7 +407,10 @@ int tv_adj_bernoulli_ll_fwd_static(int64_t n_samples, int64_t batch, int64_t max
 /* Categorical log-prob per row: ll[r] = log_softmax(logits[r,:])[target[r % target_rows]]
  * (tk.Categorical, model/struct_vae.py:258-266 and :413); optional biased variant.
  * fwd also returns the row log-sum-exp for the backward pass.
- * bwd: dlogits = dll[r] * g * (onehot - softmax), g = alpha where the biased branch was taken */
+ * bwd: dlogits = dll[r] * g * (onehot - softmax), g = alpha where the biased branch was taken.
+ * dlogits rows are dlogits_stride >= classes floats apart and the columns classes ..
+ * dlogits_stride - 1 of every row are written as zeros: with a stride that is a multiple of 4
+ * the gradient can go into tv_gemm_f32 as a 16-byte-readable operand whatever `classes` is. */
 int tv_categorical_ll_fwd(int64_t rows, int64_t classes, int64_t target_rows,
                           const float *logits, const int64_t *target, int biased, float alpha,
                           float log_threshold, float *ll, float *lse /* [rows], nullable */,
@@ -412,7 +418,7 @@ int tv_categorical_ll_fwd(int64_t rows, int64_t classes, int64_t target_rows,
 int tv_categorical_ll_bwd(int64_t rows, int64_t classes, int64_t target_rows,
                           const float *logits, const int64_t *target, int biased, float alpha,
                           float log_threshold, const float *lse, const float *dll,
-                          float *dlogits, void *stream);
+                          float *dlogits, int64_t dlogits_stride, void *stream);
 
 /* z = mean + exp(logstd) * eps ; logq[k,b] = sum_d Normal(z; mean, logstd)
  * (tk.Normal sample + log_prob, model/struct_vae.py:238-241, model/latency_vae.py:267-270).

@@ -106,6 +106,46 @@ def test_gemm_kmajor_operands_wide_form(device, m, n, k, act, strided):
     assert torch.equal(got, ops.gemm(a, b, True, False, bias=bias, **kw))       # bit-stable
 
 
+@pytest.mark.parametrize('m,n,k', [(16424, 1000, 1001), (16384, 1000, 1017), (33000, 500, 1003)])
+def test_gemm_wide_form_with_padded_rows_of_odd_length(device, m, n, k):
+    """A row-major A whose row LENGTH is not a multiple of 4 but whose row STRIDE is (the gradient
+    of the 1001-class logits, padded by the categorical backward) still takes the wide form with
+    16-byte loads: the float4 that straddles K is read, its elements beyond K are zeroed in
+    registers.  The pad columns hold NaN here, so anything that leaked would show."""
+    from tracevae_amd import ops
+    gen = torch.Generator().manual_seed(m + n + k)
+    kp = (k + 3) // 4 * 4
+    buf = torch.full([m, kp], float('nan'), device=device)
+    a = buf[:, :k]
+    a.copy_(torch.randn(m, k, generator=gen).to(device))
+    b = torch.randn(n, k, generator=gen).to(device)
+    want = a.double() @ b.double().t()
+    got = ops.gemm(a, b, False, True)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want) < TOL
+    assert torch.equal(got, ops.gemm(a, b, False, True))                # bit-stable
+    assert rel_err(ops.gemm(a.contiguous(), b, False, True), want) < TOL   # the 4-byte-load path
+
+
+def test_categorical_backward_pads_rows_with_zeros(device):
+    from tracevae_amd import hip
+    rows, classes, stride = 37, 1001, 1004
+    gen = torch.Generator().manual_seed(5)
+    logits = torch.randn(rows, classes, generator=gen).to(device)
+    target = torch.randint(0, classes, (rows,), generator=gen).to(device)
+    dll = torch.randn(rows, generator=gen).to(device)
+    lse = torch.logsumexp(logits, dim=1)
+    out = torch.full([rows, stride], float('nan'), device=device)
+    hip.call('tv_categorical_ll_bwd', rows, classes, rows, hip.ptr(logits), hip.ptr(target), 0, 1.0, 0.0,
+             hip.ptr(lse), hip.ptr(dll), hip.ptr(out), stride)
+    want = dll[:, None].double() * (F.one_hot(target, classes).double() - torch.softmax(logits.double(), dim=1))
+    assert rel_err(out[:, :classes], want) < 1e-5
+    assert torch.equal(out[:, classes:], torch.zeros(rows, stride - classes, device=device))
+    with pytest.raises(hip.HipLibraryError):
+        hip.call('tv_categorical_ll_bwd', rows, classes, rows, hip.ptr(logits), hip.ptr(target), 0, 1.0, 0.0,
+                 hip.ptr(lse), hip.ptr(dll), hip.ptr(out), classes - 1)
+
+
 def test_gemm_split_k_and_accumulate(device):
     from tracevae_amd import ops
     # weight-gradient shape: small output, long reduction -> split-K path

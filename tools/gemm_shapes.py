@@ -1,6 +1,7 @@
 """Which GEMM shapes a train step of the bench workload issues and what each costs: wraps ops.gemm
 with events (one synchronisation per call, so only the per-call device times mean anything).
-Run on the GPU box:  python tools/gemm_shapes.py"""
+Run on the GPU box:  python tools/gemm_shapes.py [V M B width z_dim]   (default 1001 100 512: the bench
+workload; 10001 500 32 1000 20: BASELINE configs[4])"""
 import collections
 import os
 import sys
@@ -18,11 +19,14 @@ def main():
     from tracevae_amd.model import TraceVAE
     from tracevae_amd.synth import SyntheticSpec, generate_flat
     from tracevae_amd.train import Trainer
-    V, M, B = 1001, 100, 512
+    argv = [int(x) for x in sys.argv[1:]]
+    V, M, B = (argv + [1001, 100, 512][len(argv):])[:3]
+    width = argv[3] if len(argv) > 3 else None
+    z_dim = argv[4] if len(argv) > 4 else 10
     dev = torch.device('cuda', 0)
-    cfg = bench.make_config()
+    cfg = bench.make_config(width, z_dim)
     spec = SyntheticSpec(num_operations=V, max_spans=M, seed=0)
-    flat, lr = generate_flat(spec, 4096, seed=1)
+    flat, lr = generate_flat(spec, max(4 * B, 256), seed=1)
     store = DeviceTraceStore(flat, lr, V)
     torch.manual_seed(0)
     vae = TraceVAE(cfg.model, V, max_node_count=M).to(dev)

@@ -30,7 +30,7 @@
 // thread owns 4 rows x 4 consecutive k of each operand:
 //   [x][k] storage: row (t>>3) + 32a, k = 4(t&7) .. +3   (one 16-byte load, or four 4-byte loads)
 //   [k][x] storage: row (t&31) + 32a, k = 4(t>>5) .. +3  (four 4-byte loads, 128 B per half-wave)
-// A small B under many rows (a layer's weights: n*k <= 4M elements, m >= 2048) is split ONCE per
+// A small B under many rows (a layer's weights: n*k <= 32M elements, m >= 2048) is split ONCE per
 // call by gemm_split_b_kernel into the LDS images of its tiles (24 KB each, in the workspace);
 // the producers then copy 96 bytes per thread and tile instead of splitting it again for each
 // of the m/128 row tiles, and a k-major weight matrix (the input-gradient product) needs no
@@ -893,9 +893,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs g) {
         v[j] = fmaxf(b, b * g.act_slope);
       }
     }
-    if (kt >= ntf) {
-      if (kq >= rem) u = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kq + 4 >= rem) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kt >= ntf) {                                   // (K need not be a multiple of 4, see run_gemm)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kq + j >= rem) u[j] = 0.f;
+        if (kq + 4 + j >= rem) v[j] = 0.f;
+      }
     }
     wide_split_store(u, v, smem + (kt & 1) * WIDE_BUF_BYTES + a_lds);
   };
@@ -1438,7 +1441,7 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
   // row tiles (a layer's weights under >= 2048 rows): 6 bytes per element of scratch
   p.planes_bytes = 0;
   // (an even number of 128-column images: the wide form takes them two at a time)
-  if (m >= 2048 && n * k <= (1ll << 22))
+  if (m >= 2048 && n * k <= (1ll << 25))
     p.planes_bytes = ((tv_cdiv(n, BN) + 1) & ~1ll) * tv_cdiv(k, BK) * (int64_t)OPERAND_BYTES;
   // the wide form: enough 128 x 256 tiles for two rounds of the chip, B pre-split, no split-K
   p.w_tiles = tv_cdiv(m, BM) * tv_cdiv(n, WBN);
@@ -1572,7 +1575,12 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   }
   // the wide form: a row-major A that can be read 16 bytes at a time against the pre-split B,
   // plain epilogue (bias at most)
-  if (plan.wide && presplit && !trans_a && g.a_vec && !row_scale && !accumulate && act_operand != 2) {
+  // (a K that is not a multiple of 4 is taken too when the rows of A are padded to one: the float4
+  // that straddles K is readable, its elements beyond K are zeroed once landed and B's planes are
+  // zero there anyway; not with a prologue, whose coefficient vectors end at K)
+  const bool a_rows16 = g.a_vec || (!trans_a && act_operand == 0 && lda % 4 == 0 &&
+                                    (((uintptr_t)a & 15) == 0) && lda >= ((k + 3) & ~3ll));
+  if (plan.wide && presplit && !trans_a && a_rows16 && !row_scale && !accumulate && act_operand != 2) {
     GemmArgs w = g;
     w.tiles_n = tv_cdiv(n, WBN);
     w.tail_first = plan.w_tail_first; w.tail_splits = plan.w_tail_splits; w.tail_kchunk = plan.w_tail_kchunk;

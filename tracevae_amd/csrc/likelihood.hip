@@ -280,13 +280,14 @@ __global__ __launch_bounds__(256) void categorical_ll_fwd_kernel(
 __global__ __launch_bounds__(256) void categorical_ll_bwd_kernel(
     int64_t rows, int64_t V, int64_t target_rows, const float *__restrict__ logits,
     const int64_t *__restrict__ target, int biased, float alpha, float log_thr,
-    const float *__restrict__ lse, const float *__restrict__ dll, float *__restrict__ dlogits) {
+    const float *__restrict__ lse, const float *__restrict__ dll, float *__restrict__ dlogits,
+    int64_t ldd) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float *x = logits + r * V;
-    float *dx = dlogits + r * V;
+    float *dx = dlogits + r * ldd;
     int64_t t = target[r % target_rows];
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
     const float ls = lse[r];
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void categorical_ll_bwd_kernel(
     if (biased && (x[t] - ls) < log_thr) g *= alpha;
     for (int64_t c = lane; c < V; c += 64)
       dx[c] = g * ((c == t ? 1.0f : 0.0f) - expf(x[c] - ls));
+    if (V + lane < ldd) dx[V + lane] = 0.f;            // the pad columns of the row (fewer than 64)
   }
 }
 
@@ -716,14 +718,18 @@ extern "C" int tv_categorical_ll_fwd(int64_t rows, int64_t classes, int64_t targ
 extern "C" int tv_categorical_ll_bwd(int64_t rows, int64_t classes, int64_t target_rows,
                                      const float *logits, const int64_t *target, int biased,
                                      float alpha, float log_threshold, const float *lse,
-                                     const float *dll, float *dlogits, void *stream) {
+                                     const float *dll, float *dlogits, int64_t dlogits_stride,
+                                     void *stream) {
   TV_REQUIRE(rows >= 0 && classes >= 1 && target_rows >= 1, "tv_categorical_ll_bwd: bad sizes");
+  TV_REQUIRE(dlogits_stride >= classes && dlogits_stride - classes < 64,
+             "tv_categorical_ll_bwd: dlogits_stride %lld must be classes .. classes + 63",
+             (long long)dlogits_stride);
   if (rows == 0) return TV_OK;
   TV_REQUIRE(rows % target_rows == 0, "tv_categorical_ll_bwd: rows must be a multiple of target_rows");
   TV_REQUIRE(logits && target && lse && dll && dlogits, "tv_categorical_ll_bwd: null pointer");
   hipLaunchKernelGGL(categorical_ll_bwd_kernel, dim3(wave_row_blocks(rows)), dim3(256), 0,
                      (hipStream_t)stream, rows, classes, target_rows, logits, target, biased, alpha,
-                     log_threshold, lse, dll, dlogits);
+                     log_threshold, lse, dll, dlogits, dlogits_stride);
   TV_LAUNCH_CHECK("tv_categorical_ll_bwd");
   return TV_OK;
 }

@@ -178,14 +178,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:
-    x = _check(x, 'x')
+    x = _rows(x, 'x')
     rows, cols = x.shape
     out = torch.empty([cols], dtype=_f32, device=x.device)
     if rows == 0:
         return out.zero_()
     wsb = hip.query('tv_colsum_workspace_bytes', rows, cols)
     ws = _workspace(wsb, x.device)
-    hip.call('tv_colsum', rows, cols, hip.ptr(x), x.stride(0), hip.ptr(out), hip.ptr(ws), wsb)
+    hip.call('tv_colsum', rows, cols, hip.ptr_rows(x), x.stride(0), hip.ptr(out), hip.ptr(ws), wsb)
     return out
 
 
@@ -338,7 +338,7 @@ class _MatmulNN(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = _check(dy, 'dy')
+        dy = _rows(dy, 'dy')          # (the categorical log-likelihood hands over padded rows)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = gemm(dy, weight, False, True)
@@ -875,11 +875,15 @@ class _CategoricalLL(Function):
         logits, target, lse = ctx.saved_tensors
         biased, alpha, log_thr = ctx.args
         dll = _check(dll, 'dll')
-        dlogits = torch.empty_like(logits)
-        hip.call('tv_categorical_ll_bwd', logits.shape[0], logits.shape[1], target.shape[0],
+        # rows padded to a multiple of 4 floats (the pad is written as zeros): the products that
+        # take this gradient (dx = dlogits . W^T over the class axis) can then read it 16 bytes
+        # at a time whatever the number of classes is (1001 operations: 4-byte loads otherwise)
+        rows, classes = logits.shape
+        padded = torch.empty([rows, (classes + 3) // 4 * 4], dtype=_f32, device=logits.device)
+        hip.call('tv_categorical_ll_bwd', rows, classes, target.shape[0],
                  hip.ptr(logits), hip.ptr(target), biased, alpha, log_thr, hip.ptr(lse),
-                 hip.ptr(dll), hip.ptr(dlogits))
-        return dlogits, None, None, None, None
+                 hip.ptr(dll), hip.ptr(padded), padded.shape[1])
+        return padded[:, :classes], None, None, None, None
 
 
 def categorical_ll(logits, target, biased: bool = False, alpha: float = 1.0,
