@@ -1466,7 +1466,7 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
   }
   if (p.w_slab_bytes > p.slab_bytes) p.slab_bytes = p.w_slab_bytes;   // either form may be taken
   p.km_splits = 0; p.km_kchunk = 0; p.km_slab_bytes = 0;
-  if (p.splits > 1 && p.planes_bytes == 0 && n > BN && 2 * p.w_tiles <= slots) {
+  if (p.planes_bytes == 0 && n > BN && 2 * p.w_tiles <= slots && p.w_tiles > 0) {
     int64_t ks = slots / p.w_tiles;                   // floor: never a second, partial round
     const int64_t kmax = k / (2 * BK);
     if (ks > kmax) ks = kmax;
