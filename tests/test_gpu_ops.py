@@ -350,7 +350,7 @@ def test_gat_conv_forward_backward(device, heads, feats, which):
 
 
 @pytest.mark.parametrize('heads,feats,k', [(2, 500, 1000), (2, 500, 41), (1, 64, 7), (4, 8, 50),
-                                           (3, 12, 33)])
+                                           (3, 12, 33), (2, 1000, 120)])
 def test_gat_layer_with_scores_as_fc_columns(device, heads, feats, k):
     """fc and the attention scores in ONE product ([ft | el | er] = x [W ; A_l W ; A_r W]^T,
     `ops.linear_scores`) read in place by the aggregation, against the oracle's GATConv on h:

@@ -22,6 +22,10 @@ constexpr int MAXH = 4;
 #ifndef TV_GAT_WAVES_PER_SIMD
 #define TV_GAT_WAVES_PER_SIMD 4
 #endif
+// rows of up to 1024 floats (CH = 4 float4 per lane) fit 128 registers; the wider form (CH = 8,
+// up to 2048 floats: the doubled widths of BASELINE configs[4]) spilled 300-540 bytes per lane
+// under that cap and ran at a third of the narrow form's memory rate, so it gets 256
+constexpr int gat_waves_per_simd(int ch) { return ch > 4 ? 2 : TV_GAT_WAVES_PER_SIMD; }
 constexpr float NEG_SLOPE = 0.2f;  // GATConv negative_slope (appendix A1)
 
 __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
@@ -121,7 +125,7 @@ struct AggArgs {
 };
 
 template <int CH, int HT, bool STATS, bool EPILOGUE>
-__global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_aggregate_fwd_kernel(AggArgs a) {
+__global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
 // attention vectors through the two GEMMs of the fc layer (tv_gat_fc_score_weight_bwd): this
 // pass then neither reads the rows of ft nor carries the attention-gradient partial sums.
 template <int CH, int HT, bool SCORE_COLS>
-__global__ __launch_bounds__(512, TV_GAT_WAVES_PER_SIMD) void gat_bwd_node_kernel(AggArgs a) {
+__global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_bwd_node_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
