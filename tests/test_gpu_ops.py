@@ -146,6 +146,31 @@ def test_categorical_backward_pads_rows_with_zeros(device):
                  hip.ptr(lse), hip.ptr(dll), hip.ptr(out), classes - 1)
 
 
+@pytest.mark.parametrize('n,offset', [(1000003, 0), (1000003, 1), (4096, 0), (5, 0), (70001, 4)])
+def test_masked_sum_of_squares(device, n, offset):
+    """tv_sumsq_partial + tv_sum_partials (the L2 term and the gradient norm of the train step):
+    16-byte loads when the pointers allow it, the scalar form otherwise, against float64."""
+    from tracevae_amd import hip
+    gen = torch.Generator().manual_seed(n + offset)
+    x = torch.randn(n + offset, generator=gen).to(device)[offset:]
+    mask = (torch.rand(n + offset, generator=gen) < 0.7).to(torch.uint8).to(device)[offset:]
+    nblk = hip.query('tv_reduce_blocks', n)
+    partial = torch.empty(nblk, dtype=torch.float64, device=device)
+    out = torch.empty(1, device=device)
+    for m, want in ((mask, (x.double() ** 2 * mask.double()).sum()), (None, (x.double() ** 2).sum())):
+        hip.call('tv_sumsq_partial', n, x.data_ptr(), 0 if m is None else m.data_ptr(), partial.data_ptr())
+        hip.call('tv_sum_partials', nblk, partial.data_ptr(), 0, out.data_ptr())
+        assert abs(float(out[0]) - float(want)) <= 2e-6 * float(want) + 1e-12
+    # y += alpha * x where the mask is on (the L2 term's gradient), same two forms
+    y0 = torch.randn(n + offset, generator=gen).to(device)[offset:]
+    for m in (mask, None):
+        y = y0.clone()
+        hip.call('tv_axpy_masked', n, 0.25, x.data_ptr(), 0 if m is None else m.data_ptr(), y.data_ptr())
+        want = torch.where(mask.bool(), torch.addcmul(y0, x, torch.tensor(0.25, device=device)), y0) \
+            if m is not None else y0 + 0.25 * x
+        assert torch.allclose(y, want, rtol=1e-6, atol=1e-6)
+
+
 def test_gemm_split_k_and_accumulate(device):
     from tracevae_amd import ops
     # weight-gradient shape: small output, long reduction -> split-K path
