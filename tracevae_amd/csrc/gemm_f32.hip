@@ -1443,9 +1443,9 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
   // (an even number of 128-column images: the wide form takes them two at a time)
   if (m >= 2048 && n * k <= (1ll << 25))
     p.planes_bytes = ((tv_cdiv(n, BN) + 1) & ~1ll) * tv_cdiv(k, BK) * (int64_t)OPERAND_BYTES;
-  // the wide form: enough 128 x 256 tiles for two rounds of the chip, B pre-split, no split-K
+  // the wide form: enough 128 x 256 tiles for one round of the chip, B pre-split, no split-K
   p.w_tiles = tv_cdiv(m, BM) * tv_cdiv(n, WBN);
-  p.wide = p.planes_bytes > 0 && p.splits == 1 && p.w_tiles >= 2 * slots && p.w_tiles < (1ll << 30);
+  p.wide = p.planes_bytes > 0 && p.splits == 1 && p.w_tiles >= slots && p.w_tiles < (1ll << 30);
   p.w_tail_first = p.w_tiles; p.w_tail_splits = 1; p.w_tail_kchunk = tv_cdiv(k, BK) * BK; p.w_slab_bytes = 0;
   if (p.wide) {
     const int64_t tail = p.w_tiles % slots;
