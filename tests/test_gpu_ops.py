@@ -125,6 +125,11 @@ def test_gemm_wide_form_with_padded_rows_of_odd_length(device, m, n, k):
     assert rel_err(got, want) < TOL
     assert torch.equal(got, ops.gemm(a, b, False, True))                # bit-stable
     assert rel_err(ops.gemm(a.contiguous(), b, False, True), want) < TOL   # the 4-byte-load path
+    # a view with the same strides whose storage ENDS with the last element must not be read past
+    flat = torch.empty((m - 1) * kp + k, device=device)
+    tight = torch.as_strided(flat, (m, k), (kp, 1))
+    tight.copy_(a)
+    assert rel_err(ops.gemm(tight, b, False, True), want) < TOL
 
 
 def test_categorical_backward_pads_rows_with_zeros(device):

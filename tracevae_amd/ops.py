@@ -145,6 +145,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
     (`tv_gemm_f32_act`)."""
     a, b = _rows(a, 'a'), _rows(b, 'b')
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    if not trans_a and k % 4 and a.stride(0) % 4 == 0 and a.stride(0) >= k + 3:
+        # the library reads such rows 16 bytes at a time, up to 3 floats past k (tracevae_hip.h):
+        # fine for a column slice of a wider buffer, not for a view whose storage ends with the
+        # last element
+        end = a.storage_offset() + (m - 1) * a.stride(0) + (k + 3) // 4 * 4
+        if end * 4 > a.untyped_storage().nbytes():
+            a = a.contiguous()
     n, kb = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
     if k != kb:
         raise ValueError(f'gemm: inner sizes differ: {k} vs {kb}')
