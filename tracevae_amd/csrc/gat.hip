@@ -508,11 +508,9 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
 //   del[u]  = sum_p dpre[rev[p]]
 //   partial sums for dattn_l (del*ft), dattn_r (der*ft), dbias (dout)
 // ------------------------------------------------------------------------------------
-// SCORE_COLS: el / er are columns of the fc product ([ft | el | er], tv_gat_fc_score_weight), so
-// their gradients del / der leave as columns of dft ([dft | del | der | 0]) and reach x, W and the
-// attention vectors through the two GEMMs of the fc layer (tv_gat_fc_score_weight_bwd): this
-// pass then neither reads the rows of ft nor carries the attention-gradient partial sums.
-template <int CH, int HT, bool SCORE_COLS>
+// (When el / er are columns of the fc product, [ft | el | er], their gradients leave as columns of
+// dft instead and steps A and B run as one pass: gat_bwd_fused_kernel below.)
+template <int CH, int HT>
 __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_bwd_node_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
@@ -609,46 +607,229 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_bwd_node_kern
     }
 
     float4 *orow = reinterpret_cast<float4 *>(a.dft + r * a.ld_dft);
-    if (SCORE_COLS) {
+    const float4 *frow = reinterpret_cast<const float4 *>(a.ft + r * a.ld_ft);
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int q = lane + 64 * c;
-        if (q < c4) orow[q] = acc[c];
-      }
-      // del | der | zeros up to a multiple of 4 columns (the GEMMs read them all)
-      const int ncol = (2 * H + 3) & ~3;
-      if (lane < ncol) {
-        float v = 0.f;
-#pragma unroll
-        for (int h = 0; h < HT; ++h) {
-          if (lane == h && h < H) v = del[h];
-          if (lane == H + h && h < H) v = der[h];
-        }
-        a.dft[r * a.ld_dft + HF + lane] = v;
-      }
-    } else {
-      const float4 *frow = reinterpret_cast<const float4 *>(a.ft + r * a.ld_ft);
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int q = lane + 64 * c;
-        if (q < c4) {
-          const float dl = sel_head<HT>(del, hc[c]), dr = sel_head<HT>(der, hc[c]);
-          const float4 wl = reinterpret_cast<const float4 *>(a.attn_l)[q];
-          const float4 wr = reinterpret_cast<const float4 *>(a.attn_r)[q];
-          orow[q] = f4_fma(dr, wr, f4_fma(dl, wl, acc[c]));
-          const float4 f = frow[q];
-          pal[c] = f4_fma(dl, f, pal[c]);
-          par[c] = f4_fma(dr, f, par[c]);
-        }
+    for (int c = 0; c < CH; ++c) {
+      const int q = lane + 64 * c;
+      if (q < c4) {
+        const float dl = sel_head<HT>(del, hc[c]), dr = sel_head<HT>(der, hc[c]);
+        const float4 wl = reinterpret_cast<const float4 *>(a.attn_l)[q];
+        const float4 wr = reinterpret_cast<const float4 *>(a.attn_r)[q];
+        orow[q] = f4_fma(dr, wr, f4_fma(dl, wl, acc[c]));
+        const float4 f = frow[q];
+        pal[c] = f4_fma(dl, f, pal[c]);
+        par[c] = f4_fma(dr, f, par[c]);
       }
     }
   }
 
-  if (!SCORE_COLS) {
-    float4 v[2][CH];
+  float4 v[2][CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { v[0][c] = pal[c]; v[1][c] = par[c]; }
-    block_col_reduce<2, CH>(lds, v, c4, a.partial + (int64_t)blockIdx.x * 3 * HF);
+  for (int c = 0; c < CH; ++c) { v[0][c] = pal[c]; v[1][c] = par[c]; }
+  block_col_reduce<2, CH>(lds, v, c4, a.partial + (int64_t)blockIdx.x * 3 * HF);
+}
+
+// ------------------------------------------------------------------------------------
+// backward with the score gradients as columns of dft ([dft | del | der | 0], the el / er columns
+// of the fc product: tv_gat_fc_score_weight), both steps in ONE pass over
+// the rows: the graph is symmetric, so the in-neighbours of u (step A gathers their ft rows for
+// the score gradients of u's in-edges) are also its out-neighbours (step B gathers their dout
+// rows for dft[u]).  One wave per row u reads dout[u], then ft[s_j] and dout[s_j] of every
+// neighbour together: dout is then fetched from memory once (the own-row read and the gathered
+// reads of the same rows meet in the L2; u is its own neighbour through the self-loop) where
+// the two-kernel form read it in both, 205 MB apart.  What cannot ride along is del[u], the sum
+// of dpre over the edges OUT of u: those belong to other rows' softmax and are finished only
+// when the pass is; gat_bwd_score_cols_kernel adds them up afterwards (edge scalars only) and
+// writes the [del | der | 0] columns.
+// ------------------------------------------------------------------------------------
+template <int CH, int HT>
+__global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const int H = a.H, F = a.F, c4 = a.c4;
+  const int64_t HF = (int64_t)H * F;
+  int hc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) hc[c] = ((lane + 64 * c) * 4) / F;
+
+  float4 pb[CH];                                     // dbias = column sums of dout
+#pragma unroll
+  for (int c = 0; c < CH; ++c) pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int64_t r = wave; r < a.rows; r += nwaves) {  // (a single replica: row = node)
+    const int64_t p0 = a.indptr[r];
+    const int deg = (int)(a.indptr[r + 1] - p0);
+
+    float4 d[CH], acc[CH];
+    const float4 *drow = reinterpret_cast<const float4 *>(a.dout + r * HF);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int q = lane + 64 * c;
+      d[c] = (q < c4) ? drow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[c] = f4_add(pb[c], d[c]);
+      acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    float sacc[HT], gkeep[HT];
+#pragma unroll
+    for (int h = 0; h < HT; ++h) sacc[h] = gkeep[h] = 0.f;
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+      const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
+      const int j = c0 + lane;
+      int64_t s = 0;
+      float al[HT], gj[HT];
+#pragma unroll
+      for (int h = 0; h < HT; ++h) al[h] = gj[h] = 0.f;
+      if (j < deg) {
+        s = a.indices[p0 + j];
+        const int64_t rp = a.rev[p0 + j];            // the opposite edge u -> s_j
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+          if (h < H) al[h] = a.alpha_in[rp * H + h];
+      }
+      // U neighbours per trip: their 2U rows (ft and dout) in flight together
+      auto edges = [&](auto nconst, int jj) {
+        constexpr int U = decltype(nconst)::value;
+        float4 x[U][CH], y[U][CH];
+        float aj[U][HT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t sj = __shfl(s, jj + u, 64);
+#pragma unroll
+          for (int h = 0; h < HT; ++h) aj[u][h] = __shfl(al[h], jj + u, 64);
+          const float4 *frow = reinterpret_cast<const float4 *>(a.ft + sj * a.ld_ft);
+          const float4 *wrow = reinterpret_cast<const float4 *>(a.dout + sj * HF);
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const int q = lane + 64 * c;
+            x[u][c] = (q < c4) ? frow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            y[u][c] = (q < c4) ? wrow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        float part[U][HT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int h = 0; h < HT; ++h) part[u][h] = 0.f;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const float dp = f4_dot(d[c], x[u][c]);
+#pragma unroll
+            for (int h = 0; h < HT; ++h) part[u][h] += (hc[c] == h) ? dp : 0.f;
+            acc[c] = f4_fma(sel_head<HT>(aj[u], hc[c]), y[u][c], acc[c]);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+          if (h < H) {
+            float tot[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) tot[u] = tv_wave_sum(part[u][h]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (lane == jj + u) gj[h] = tot[u];
+          }
+        }
+      };
+      // (one neighbour per trip: two per trip, four rows in flight, cost a wave per SIMD in
+      // registers and measured 1.3 % slower on the step)
+      for (int jj = 0; jj < cnt; ++jj) edges(std::integral_constant<int, 1>(), jj);
+      if (j < deg) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+          if (h < H) {
+            sacc[h] += a.alpha_in[(p0 + j) * H + h] * gj[h];
+            if (deg > 64) a.dpre[(p0 + j) * H + h] = gj[h];
+            gkeep[h] = gj[h];
+          }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < HT; ++h) sacc[h] = tv_wave_sum(sacc[h]);
+
+    // softmax + LeakyReLU backward of the in-edges (as gat_bwd_edge_kernel)
+    float dsum[HT];
+#pragma unroll
+    for (int h = 0; h < HT; ++h) dsum[h] = 0.f;
+    for (int c0 = 0; c0 < deg; c0 += 64) {
+      const int j = c0 + lane;
+      if (j < deg) {
+        const int64_t s = a.indices[p0 + j];
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+          if (h < H) {
+            const float g = (deg > 64) ? a.dpre[(p0 + j) * H + h] : gkeep[h];
+            const float alj = a.alpha_in[(p0 + j) * H + h];
+            const float pre = a.el[s * a.ld_e + h] + a.er[r * a.ld_e + h];
+            const float dp = alj * (g - sacc[h]) * (pre > 0.f ? 1.f : NEG_SLOPE);
+            a.dpre[(p0 + j) * H + h] = dp;
+            dsum[h] += dp;
+          }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < HT; ++h) {
+      if (h < H) {
+        const float tot = tv_wave_sum(dsum[h]);
+        if (lane == 0) a.der[r * H + h] = tot;
+      }
+    }
+
+    float4 *orow = reinterpret_cast<float4 *>(a.dft + r * a.ld_dft);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int q = lane + 64 * c;
+      if (q < c4) orow[q] = acc[c];
+    }
+  }
+
+  float4 vb[1][CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) vb[0][c] = pb[c];
+  block_col_reduce<1, CH>(lds, vb, c4, a.partial + ((int64_t)blockIdx.x * 3 + 2) * HF);
+}
+
+// [del | der | 0] behind the HF gradient columns of every dft row: del[u] = sum of dpre over the
+// edges out of u (the opposites, rev[p], of its in-edges), der[u] from the pass above
+__global__ __launch_bounds__(256) void gat_bwd_score_cols_kernel(AggArgs a) {
+  // four lanes per row, each takes every fourth in-edge (a span has few neighbours: one dependent
+  // rev -> dpre chain per lane), summed by two shuffles in a fixed order
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = t >> 2;
+  const int k = (int)(t & 3);
+  const bool live = r < a.rows;
+  const int H = a.H;
+  float del[MAXH];
+#pragma unroll
+  for (int h = 0; h < MAXH; ++h) del[h] = 0.f;
+  if (live) {
+    const int64_t p0 = a.indptr[r], p1 = a.indptr[r + 1];
+    for (int64_t p = p0 + k; p < p1; p += 4) {
+      const int64_t rp = a.rev[p];
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h)
+        if (h < H) del[h] += a.dpre[rp * H + h];
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < MAXH; ++h) {
+    del[h] += __shfl_xor(del[h], 1, 64);
+    del[h] += __shfl_xor(del[h], 2, 64);
+  }
+  if (!live) return;
+  float *o = a.dft + r * a.ld_dft + (int64_t)H * a.F;
+  const int ncol = (2 * H + 3) & ~3;
+  for (int c = k; c < ncol; c += 4) {                // lane k writes columns k, k + 4, ...
+    float v = 0.f;
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) {
+      if (c == h && h < H) v = del[h];
+      if (c == H + h && h < H) v = a.der[r * H + h];
+    }
+    o[c] = v;
   }
 }
 
@@ -945,21 +1126,17 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gat_aggregate_bwd: workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const bool big = a.c4 > 256;
-  {
-    // same grid as the node pass: both write their column partials into slot blockIdx.x
-    const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
-    const size_t ldsb = sizeof(float) * HF;
-    TV_GAT_LAUNCH(gat_bwd_edge_kernel, grid, block, ldsb, s, a);
+  const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
+  if (score_grad_columns) {
+    TV_GAT_LAUNCH(gat_bwd_fused_kernel, grid, block, sizeof(float) * HF, s, a);
+    TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(fused)");
+    hipLaunchKernelGGL(gat_bwd_score_cols_kernel, dim3((unsigned)tv_cdiv(4 * rows, 256)), dim3(256), 0, s, a);
+    TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(score columns)");
+  } else {
+    // same grid for both passes: they write their column partials into slot blockIdx.x
+    TV_GAT_LAUNCH(gat_bwd_edge_kernel, grid, block, sizeof(float) * HF, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(edge)");
-  }
-  {
-    const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
-    const size_t ldsb = sizeof(float) * 2 * HF;
-    if (score_grad_columns) {
-      TV_GAT_LAUNCH(gat_bwd_node_kernel, grid, block, 0, s, a, , true);
-    } else {
-      TV_GAT_LAUNCH(gat_bwd_node_kernel, grid, block, ldsb, s, a, , false);
-    }
+    TV_GAT_LAUNCH(gat_bwd_node_kernel, grid, block, sizeof(float) * 2 * HF, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(node)");
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(tv_slot_grid(3 * HF)), dim3(256), 0, s,
