@@ -453,6 +453,20 @@ def test_gat_high_degree(device):
         assert rel_err(got, ref) < TOL
         assert rel_err(ftd.grad, ftr.grad) < TOL
         assert rel_err(ald.grad, alr.grad) < TOL and rel_err(ard.grad, arr.grad) < TOL
+        # the same star through the layer form (scores and their gradients as columns): the fused
+        # backward pass keeps a row's per-edge dot products in memory when it has more than 64
+        k = 24
+        x, w = _rand(rows, k, seed=11), _rand(heads * feats, k, seed=12)
+        xr, wr, alr, arr, br = (t.clone().requires_grad_(True) for t in (x, w, al, ar, bias))
+        ref = gat_conv(xr, src, dst, wr, alr, arr, br, heads).reshape(rows, -1)
+        ref.backward(g)
+        xd, wd, ald, ard, bd = (_dev(t, device).requires_grad_(True) for t in (x, w, al, ar, bias))
+        got, _ = ops.gat_conv(ops.linear_scores(xd, wd, ald, ard), ald, ard, bd, graph, 1)
+        got.backward(_dev(g, device))
+        assert rel_err(got, ref) < TOL
+        for a_, b_ in ((xd.grad, xr.grad), (wd.grad, wr.grad), (ald.grad, alr.grad), (ard.grad, arr.grad),
+                       (bd.grad, br.grad)):
+            assert rel_err(a_, b_) < TOL
 
 
 def test_gat_replicas_and_eval_epilogue(device):
