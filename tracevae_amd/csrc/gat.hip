@@ -26,6 +26,26 @@ constexpr int MAXH = 4;
 // up to 2048 floats: the doubled widths of BASELINE configs[4]) spilled 300-540 bytes per lane
 // under that cap and ran at a third of the narrow form's memory rate, so it gets 256
 constexpr int gat_waves_per_simd(int ch) { return ch > 4 ? 2 : TV_GAT_WAVES_PER_SIMD; }
+
+// The rows a wave walks.  Workgroups go to the eight XCDs round-robin (id mod 8), and a row's
+// neighbours sit a few rows away (a trace's spans are contiguous), so with rows dealt out
+// wave by wave over the whole grid a gathered row was fetched into 1.4-1.5 L2s on average
+// (PMC: 281 MB read by the forward pass for 205 MB of ft).  Each XCD therefore owns one
+// contiguous eighth of the rows and its workgroups stride over that eighth only.
+struct RowWalk { int64_t beg, end, step; };
+__device__ __forceinline__ RowWalk row_walk(int64_t rows, int nw) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t g = gridDim.x, b = blockIdx.x;
+  RowWalk k;
+  if ((g & 7) != 0) {                                // few rows: the plain deal
+    k.beg = b * nw + w; k.end = rows; k.step = g * nw;
+    return k;
+  }
+  const int64_t per = (rows + 7) >> 3;
+  const int64_t lo = (b & 7) * per, hi = lo + per < rows ? lo + per : rows;
+  k.beg = lo + (b >> 3) * nw + w; k.end = hi; k.step = (g >> 3) * nw;
+  return k;
+}
 constexpr float NEG_SLOPE = 0.2f;  // GATConv negative_slope (appendix A1)
 
 __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 y) {
@@ -129,8 +149,7 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const RowWalk rw = row_walk(a.rows, nw);
   const int H = a.H, F = a.F, c4 = a.c4;
   const int64_t HF = (int64_t)H * F;
 
@@ -149,18 +168,18 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd
   // and the neighbour index of the next row are loaded while this row is being gathered.
   int64_t p0_b = 0, s_b = 0, p0_a = 0;
   int deg_b = 0, deg_a = 0;
-  if (wave < a.rows) {
-    const int64_t v = wave % a.rows_per_rep;
+  if (rw.beg < rw.end) {
+    const int64_t v = rw.beg % a.rows_per_rep;
     p0_b = a.indptr[v];
     deg_b = (int)(a.indptr[v + 1] - p0_b);
     s_b = (lane < deg_b) ? a.indices[p0_b + lane] : 0;
   }
-  if (wave + nwaves < a.rows) {
-    const int64_t v = (wave + nwaves) % a.rows_per_rep;
+  if (rw.beg + rw.step < rw.end) {
+    const int64_t v = (rw.beg + rw.step) % a.rows_per_rep;
     p0_a = a.indptr[v];
     deg_a = (int)(a.indptr[v + 1] - p0_a);
   }
-  for (int64_t r = wave; r < a.rows; r += nwaves) {
+  for (int64_t r = rw.beg; r < rw.end; r += rw.step) {
     const int64_t rep = r / a.rows_per_rep;
     const int64_t v = r - rep * a.rows_per_rep;
     const int64_t base = rep * a.rows_per_rep;
@@ -169,9 +188,9 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd
     const int64_t s_rel = s_b;
     p0_b = p0_a;
     deg_b = deg_a;
-    if (r + nwaves < a.rows) s_b = (lane < deg_b) ? a.indices[p0_b + lane] : 0;
-    if (r + 2 * nwaves < a.rows) {
-      const int64_t v2 = (r + 2 * nwaves) % a.rows_per_rep;
+    if (r + rw.step < rw.end) s_b = (lane < deg_b) ? a.indices[p0_b + lane] : 0;
+    if (r + 2 * rw.step < rw.end) {
+      const int64_t v2 = (r + 2 * rw.step) % a.rows_per_rep;
       p0_a = a.indptr[v2];
       deg_a = (int)(a.indptr[v2 + 1] - p0_a);
     }
@@ -365,8 +384,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const RowWalk rw = row_walk(a.rows, nw);
   const int H = a.H, F = a.F, c4 = a.c4;
   const int64_t HF = (int64_t)H * F;
   int hc[CH];
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(512) void gat_bwd_edge_kernel(AggArgs a) {
 #pragma unroll
   for (int c = 0; c < CH; ++c) pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int64_t r = wave; r < a.rows; r += nwaves) {
+  for (int64_t r = rw.beg; r < rw.end; r += rw.step) {
     const int64_t rep = r / a.rows_per_rep;
     const int64_t v = r - rep * a.rows_per_rep;
     const int64_t base = rep * a.rows_per_rep;
@@ -515,8 +533,7 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_bwd_node_kern
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const RowWalk rw = row_walk(a.rows, nw);
   const int H = a.H, F = a.F, c4 = a.c4;
   const int64_t HF = (int64_t)H * F;
   int hc[CH];
@@ -527,7 +544,7 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_bwd_node_kern
 #pragma unroll
   for (int c = 0; c < CH; ++c) pal[c] = par[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int64_t r = wave; r < a.rows; r += nwaves) {
+  for (int64_t r = rw.beg; r < rw.end; r += rw.step) {
     const int64_t rep = r / a.rows_per_rep;
     const int64_t u = r - rep * a.rows_per_rep;
     const int64_t base = rep * a.rows_per_rep;
@@ -647,8 +664,7 @@ __global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * nw + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * nw;
+  const RowWalk rw = row_walk(a.rows, nw);
   const int H = a.H, F = a.F, c4 = a.c4;
   const int64_t HF = (int64_t)H * F;
   int hc[CH];
@@ -659,7 +675,7 @@ __global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
 #pragma unroll
   for (int c = 0; c < CH; ++c) pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int64_t r = wave; r < a.rows; r += nwaves) {  // (a single replica: row = node)
+  for (int64_t r = rw.beg; r < rw.end; r += rw.step) {  // (a single replica: row = node)
     const int64_t p0 = a.indptr[r];
     const int deg = (int)(a.indptr[r + 1] - p0);
 
@@ -735,7 +751,7 @@ __global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
         }
       };
       // (one neighbour per trip: two per trip, four rows in flight, cost a wave per SIMD in
-      // registers and measured 1.3 % slower on the step)
+      // registers and measured 1.3-1.8 % slower on the step, before and after the XCD-aware walk)
       for (int jj = 0; jj < cnt; ++jj) edges(std::integral_constant<int, 1>(), jj);
       if (j < deg) {
 #pragma unroll
