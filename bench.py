@@ -37,7 +37,7 @@ GEMM_DTYPE = 'f32 via bf16x3 split, 6 terms, fp32 accumulate'
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per GEMM launch of the default workload, from the committed --pmc passes
 # (tools/summarize_profile.py traffic; FETCH_SIZE x2 + WRITE_SIZE, separate passes)
-TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r02h_hbm_traffic.json')
+TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r02i_hbm_traffic.json')
 
 
 def measured_traffic(args):
@@ -349,7 +349,7 @@ def main():
                     'peak_is': 'dense bf16 MFMA peak (2500 TFLOP/s) / 6 partial products; achieved '
                                'counts algorithmic 2*M*N*K flops',
                     'frac': tf / GEMM_PEAK_TFLOPS, 'traffic': measured_traffic(args),
-                    'traffic_unit': 'bytes/launch (profiles/r02h_hbm_traffic.json)',
+                    'traffic_unit': 'bytes/launch (profiles/r02i_hbm_traffic.json)',
                     'launches': g[0], 'avg_ms': g[2] / max(g[0], 1),
                     'share_of_step': g[2] * 1e-3 / elapsed}
             # the same figure for the shapes that carry the time (the aggregate above also
