@@ -259,9 +259,17 @@ __global__ __launch_bounds__(256) void categorical_ll_fwd_kernel(
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float *x = logits + r * V;
     float m = -INFINITY, s = 0.f;
-    for (int64_t c = lane; c < V; c += 64) {
-      const float v = x[c];
-      if (v > m) { s = s * expf(m - v) + 1.0f; m = v; } else { s += expf(v - m); }
+    // eight loads in flight per lane (one load per trip behind the branchy update streamed the
+    // 5 GB of K = 100 scoring logits at 2.6 TB/s)
+    for (int64_t c0 = lane; c0 < V; c0 += 64 * 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (c0 + 64 * k < V) ? x[c0 + 64 * k] : -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (v[k] > m) { s = s * expf(m - v[k]) + 1.0f; m = v[k]; }
+        else if (v[k] != -INFINITY) { s += expf(v[k] - m); }
+      }
     }
     const float mm = tv_wave_max(m);
     s = tv_wave_sum(m == -INFINITY ? 0.f : s * expf(m - mm));
