@@ -469,12 +469,13 @@ def test_gat_high_degree(device):
             assert rel_err(a_, b_) < TOL
 
 
-def test_gat_replicas_and_eval_epilogue(device):
+@pytest.mark.parametrize('K', [3, 9])        # (from 8 replicas on the output rows are streamed)
+def test_gat_replicas_and_eval_epilogue(device, K):
     """K replicas of the decoder graph in one launch + fused eval BatchNorm/LeakyReLU."""
     from oracle.model import gat_conv
     from tracevae_amd import ops
     db, ob = _graph(device)
-    heads, feats, K = 2, 12, 3
+    heads, feats = 2, 12
     graph = db.dec
     src, dst = torch.as_tensor(ob['dec_src']), torch.as_tensor(ob['dec_dst'])
     rows = graph.num_rows

@@ -359,7 +359,15 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd
           o.z = tv_lrelu(fmaf(o.z, sc.z, sh.z), a.ep_slope);
           o.w = tv_lrelu(fmaf(o.w, sc.w, sh.w), a.ep_slope);
         }
-        orow[q] = o;
+        // many replicas (K-sample scoring: gigabytes of output that no cache will hold for the
+        // next kernel): stream the rows past the L2, which then keeps the gathered rows
+        if (EPILOGUE && a.n_rep >= 8) {
+          typedef float f32x4_t __attribute__((ext_vector_type(4)));
+          const f32x4_t ov = {o.x, o.y, o.z, o.w};
+          __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t *>(orow + q));
+        } else {
+          orow[q] = o;
+        }
       }
     }
   }
