@@ -176,6 +176,60 @@ def test_masked_sum_of_squares(device, n, offset):
         assert torch.allclose(y, want, rtol=1e-6, atol=1e-6)
 
 
+def test_gemm_kmajor_wide_form_random_shapes(device):
+    """32 seeded random weight-gradient shapes inside the wide k-major form's conditions (M, N
+    multiples of 4, N > 128, few enough tiles for a split over K), with and without the prologue,
+    against float64: unit boundaries, partial k-tiles and edge tiles fall everywhere."""
+    from tracevae_amd import ops
+    rng = np.random.RandomState(20261111)
+    for case in range(32):
+        m = 4 * int(rng.randint(1, 380))
+        n = 4 * int(rng.randint(33, 380))
+        k = int(rng.randint(130, 9000))
+        gen = torch.Generator().manual_seed(case)
+        a = torch.randn(k, m, generator=gen).to(device)
+        b = torch.randn(k, n, generator=gen).to(device)
+        Bm, kw = b.double(), {}
+        if case % 2:
+            scale = (0.5 + torch.rand(n, generator=gen)).to(device)
+            shift = (0.3 * torch.randn(n, generator=gen)).to(device)
+            kw['act'] = (2, scale, shift, 0.01)
+            Bm = F.leaky_relu(Bm * scale.double() + shift.double(), 0.01)
+        want = a.double().t() @ Bm
+        got = ops.gemm(a, b, True, False, **kw)
+        assert rel_err(got, want) < 2e-5, (m, n, k, case)
+
+
+def test_gemm_wide_form_random_shapes(device):
+    """12 seeded random layer-product shapes that take the wide form (many rows of a row-major A
+    against a small B in either storage order), K any length under a row stride padded to 4
+    floats, with bias, alternately with the prologue on A when K allows it; against float64."""
+    from tracevae_amd import ops
+    rng = np.random.RandomState(7)
+    for case in range(12):
+        n = int(rng.randint(600, 1100))
+        m = 128 * int(rng.randint(256 * 256 // ((n + 255) // 256 * 256) + 1, 200)) + int(rng.randint(0, 128))
+        k = int(rng.randint(40, 1100))
+        tb = bool(case & 1)
+        gen = torch.Generator().manual_seed(100 + case)
+        kp = (k + 3) // 4 * 4
+        buf = torch.full([m, kp], float('nan'), device=device)
+        a = buf[:, :k]
+        a.copy_(torch.randn(m, k, generator=gen).to(device))
+        b = torch.randn(*((n, k) if tb else (k, n)), generator=gen).to(device)
+        bias = torch.randn(n, generator=gen).to(device)
+        A, kw = a.double(), {}
+        if case % 3 == 0 and k % 4 == 0:
+            scale = (0.5 + torch.rand(k, generator=gen)).to(device)
+            shift = (0.3 * torch.randn(k, generator=gen)).to(device)
+            kw['act'] = (1, scale, shift, 0.01)
+            A = F.leaky_relu(A * scale.double() + shift.double(), 0.01)
+        want = A @ (b.double().t() if tb else b.double()) + bias.double()
+        got = ops.gemm(a, b, False, tb, bias=bias, **kw)
+        assert torch.isfinite(got).all(), (m, n, k, case)
+        assert rel_err(got, want) < 2e-5, (m, n, k, case)
+
+
 def test_gemm_split_k_and_accumulate(device):
     from tracevae_amd import ops
     # weight-gradient shape: small output, long reduction -> split-K path
