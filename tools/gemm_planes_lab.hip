@@ -18,7 +18,12 @@
 #include <cstdint>
 #include <cmath>
 #include <vector>
+#include <type_traits>
+#include <utility>
 
+#ifndef BB_EXP
+#define BB_EXP 0   // 1: no barrier, 2: no DMA inside the k-loop (timing only, results wrong)
+#endif
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -338,6 +343,148 @@ __global__ __launch_bounds__(512) void gemm_split_a_kernel(const float *A, int64
   }
 }
 
+// Fourth form: ONE multiplying wave per SIMD with the whole register file (256 threads, 512
+// registers per lane: 256 accumulators + two sets of fragments), a 128 x 64 block per wave, 256 x 128
+// tile, both operands as ready-made plane images by LDS-DMA.  36 ds_read_b128 feed 96 matrix
+// instructions per wave and k-tile (0.375 per instruction against 0.5 for the 64 x 64 blocks of the
+// forms above), and the workgroup reads 144 KB of LDS per k-tile instead of 192.  There is no second
+// wave to cover a wait, so the reads of one k-step are issued under the matrix instructions of the
+// other, and the barrier sits between the two k-steps of a tile: by then the DMA of the next tile
+// has had a whole k-step to land and this wave's reads of the current one are all issued.
+__global__ __launch_bounds__(256) void gemm_big_block_kernel(const char *A, const char *B, float *C, int64_t M,
+                                                             int64_t N, int64_t ldc, int tiles_m, int tiles_n,
+                                                             int ktiles) {
+  extern __shared__ __align__(16) char smem[];        // 2 x (B image | A image 0 | A image 1)
+  constexpr int BUF_BYTES = 3 * OPERAND_BYTES;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = (tiles_m / 2) * tiles_n;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int per = ntiles >> 3;
+    const int L = (tile & 7) * per + (tile >> 3);
+    const int tn = L % tiles_n, tm = L / tiles_n;
+    const char *a_img = A + (int64_t)(2 * tm) * ktiles * OPERAND_BYTES;
+    const char *b_img = B + (int64_t)tn * ktiles * OPERAND_BYTES;
+    const int64_t as = (int64_t)ktiles * OPERAND_BYTES;
+    f32x16 hi[4][2], lo[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+    bf16x8 X0[4][3], Y0[2][3], X1[4][3], Y1[2][3];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned dma_voff = (unsigned)(wave * 6 * 1024 + lane * 16), dma_loff = (unsigned)(wave * 6 * 1024);
+    const unsigned rd_b[2] = {plane_offset(wn * 64 + (lane & 31), 2 * (lane >> 5)),
+                              plane_offset(wn * 64 + 32 + (lane & 31), 2 * (lane >> 5))};
+    // read R of a k-step: plane R % 3 of fragment set R / 3 (sets 0, 1: B columns; 2..5: A rows)
+    auto one_read = [&](auto rc, const char *buf, int step, bf16x8 (&X)[4][3], bf16x8 (&Y)[2][3]) {
+      constexpr int R = decltype(rc)::value, SET = R / 3, PL = R % 3;
+      if constexpr (SET < 2) {
+        const char *p = buf + plane_offset(wn * 64 + 32 * SET + (lane & 31), 2 * (2 * step + (lane >> 5)));
+        Y[SET][PL] = *reinterpret_cast<const bf16x8 *>(p + PL * PLANE_BYTES);
+      } else {
+        const char *p = buf + (1 + wm) * OPERAND_BYTES +
+                        plane_offset(32 * (SET - 2) + (lane & 31), 2 * (2 * step + (lane >> 5)));
+        X[SET - 2][PL] = *reinterpret_cast<const bf16x8 *>(p + PL * PLANE_BYTES);
+      }
+    };
+    // matrix instruction K of a k-step: term K % 6 of block K / 6 (blocks walk i = 0..3, j in a snake)
+    auto one_mfma = [&](auto kc, bf16x8 (&X)[4][3], bf16x8 (&Y)[2][3]) {
+      constexpr int K = decltype(kc)::value, BLK = K / 6, TERM = K % 6, I = BLK >> 1;
+      constexpr int J = (I & 1) ? 1 - (BLK & 1) : (BLK & 1);
+      constexpr int AP = TERM == 0 ? 2 : (TERM == 1 ? 0 : (TERM == 2 ? 1 : (TERM == 3 ? 1 : 0)));
+      constexpr int BP = TERM == 0 ? 0 : (TERM == 1 ? 2 : (TERM == 2 ? 1 : (TERM == 3 ? 0 : (TERM == 4 ? 1 : 0))));
+      if constexpr (TERM < 5) lo[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[I][AP], Y[J][BP], lo[I][J], 0, 0, 0);
+      else hi[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[I][0], Y[J][0], hi[I][J], 0, 0, 0);
+    };
+    // DMA Q of a k-tile: chunk Q % 6 of this wave's share of image Q / 6 (B, A0, A1)
+    auto one_dma = [&](auto qc, int kt, char *buf) {
+      constexpr int Q = decltype(qc)::value, IMG = Q / 6, C = Q % 6;
+      const char *src = (IMG == 0 ? b_img : a_img + (int64_t)(IMG - 1) * as) + (int64_t)kt * OPERAND_BYTES;
+      __builtin_amdgcn_global_load_lds((const void *)(src + dma_voff + C * 1024),
+                                       (lds_void *)(buf + IMG * OPERAND_BYTES + dma_loff + C * 1024), 16, 0, 0);
+    };
+    (void)rd_b;
+    // one k-step: 48 matrix instructions on (Xm, Ym) with the 18 reads of the other k-step's
+    // fragments (and, when DMA, the 18 DMAs of the tile after next) dealt out between them
+    auto kstep = [&](auto dmac, bf16x8 (&Xm)[4][3], bf16x8 (&Ym)[2][3], const char *rbuf, int rstep,
+                     bf16x8 (&Xr)[4][3], bf16x8 (&Yr)[2][3], int kt, char *dbuf) {
+      constexpr bool DMA = decltype(dmac)::value;
+      auto group = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int K0 = (Q / 3) * 8 + (Q % 3) * 3;   // 3, 3, 2 matrix instructions per group
+        one_read(qc, rbuf, rstep, Xr, Yr);
+        one_mfma(std::integral_constant<int, K0>(), Xm, Ym);
+        if constexpr (DMA && BB_EXP != 2) one_dma(qc, kt, dbuf);
+        one_mfma(std::integral_constant<int, K0 + 1>(), Xm, Ym);
+        if constexpr (Q % 3 != 2) one_mfma(std::integral_constant<int, K0 + 2>(), Xm, Ym);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      group(std::integral_constant<int, 0>()); group(std::integral_constant<int, 1>());
+      group(std::integral_constant<int, 2>()); group(std::integral_constant<int, 3>());
+      group(std::integral_constant<int, 4>()); group(std::integral_constant<int, 5>());
+      group(std::integral_constant<int, 6>()); group(std::integral_constant<int, 7>());
+      group(std::integral_constant<int, 8>()); group(std::integral_constant<int, 9>());
+      group(std::integral_constant<int, 10>()); group(std::integral_constant<int, 11>());
+      group(std::integral_constant<int, 12>()); group(std::integral_constant<int, 13>());
+      group(std::integral_constant<int, 14>()); group(std::integral_constant<int, 15>());
+      group(std::integral_constant<int, 16>()); group(std::integral_constant<int, 17>());
+    };
+    auto frags = [&](const char *buf, int step, bf16x8 (&X)[4][3], bf16x8 (&Y)[2][3]) {
+      const char *As = buf + (1 + wm) * OPERAND_BYTES;
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) read_set(buf, wn * 64 + 32 * j2, lane, step, Y[j2]);
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) read_set(As, 32 * i2, lane, step, X[i2]);
+    };
+    auto multiply = [&](bf16x8 (&X)[4][3], bf16x8 (&Y)[2][3]) {
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) mma6(X[i2], Y[(i2 & 1) ? 1 - j2 : j2], hi[i2][(i2 & 1) ? 1 - j2 : j2], lo[i2][(i2 & 1) ? 1 - j2 : j2]);
+    };
+    __builtin_amdgcn_s_barrier();                      // previous tile's last reads are done
+    stage<3, 4>(b_img, a_img, as, smem, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ktiles > 1) stage<3, 4>(b_img + OPERAND_BYTES, a_img + OPERAND_BYTES, as, smem + BUF_BYTES, wave, lane);
+    frags(smem, 0, X0, Y0);
+    for (int it = 0; it + 1 < ktiles; ++it) {          // (no branches inside: one scheduling region per k-step)
+      char *cur = smem + (it & 1) * BUF_BYTES, *nxt = smem + ((it + 1) & 1) * BUF_BYTES;
+      const int kt = it + 2 < ktiles ? it + 2 : ktiles - 1;   // (the last one is a repeat, never read)
+      kstep(std::false_type(), X0, Y0, cur, 1, X1, Y1, 0, nullptr);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile it + 1 has landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's reads of tile it are done
+#if BB_EXP != 1
+      __builtin_amdgcn_s_barrier();
+#endif
+      asm volatile("" ::: "memory");
+      kstep(std::true_type(), X1, Y1, nxt, 0, X0, Y0, kt, cur);
+    }
+    {
+      char *cur = smem + ((ktiles - 1) & 1) * BUF_BYTES;
+      kstep(std::false_type(), X0, Y0, cur, 1, X1, Y1, 0, nullptr);
+      multiply(X1, Y1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the repeated DMA, before the buffers are reused)
+    }
+    const int kh = lane >> 5, xl = lane & 31;
+    const int64_t m0 = (int64_t)tm * 2 * BM, n0 = (int64_t)tn * BN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 32 + xl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * 128 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+          if (row < M && col < N) C[row * ldc + col] = hi[i][j][r] + lo[i][j][r];
+        }
+      }
+  }
+}
+
 int main(int argc, char **argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 51200, N = argc > 2 ? atoll(argv[2]) : 1024;
   const int64_t K = argc > 3 ? atoll(argv[3]) : 1024;
@@ -404,6 +551,26 @@ int main(int argc, char **argv) {
       ms /= reps;
       printf("%-44s %lld x %lld x %lld  %.3f ms  %.1f TF (six-term work)\n",
              persist ? "128x256, 8 waves split A themselves, persist." : "128x256, 8 waves split A themselves",
+             (long long)M, (long long)N, (long long)K, ms, 2.0 * M * N * K / ms / 1e9);
+    }
+  }
+  if (tiles_m % 2 == 0 && ((tiles_m / 2) * tiles_n) % 8 == 0) {
+    const size_t lds = 2 * 3 * (size_t)OPERAND_BYTES;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_big_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int persist = 0; persist < 2; ++persist) {
+      const int grid = persist ? 256 : (tiles_m / 2) * tiles_n;
+      CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+      for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL(gemm_big_block_kernel, dim3(grid), dim3(256), lds, 0, pA, pB, dC, M, N, N, tiles_m, tiles_n, ktiles);
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipEventRecord(e0));
+      for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(gemm_big_block_kernel, dim3(grid), dim3(256), lds, 0, pA, pB, dC, M, N, N, tiles_m, tiles_n, ktiles);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+      printf("%-44s %lld x %lld x %lld  %.3f ms  %.1f TF (six-term work)\n",
+             persist ? "256x128, 4 waves of 128x64, persistent" : "256x128, 4 waves of 128x64",
              (long long)M, (long long)N, (long long)K, ms, 2.0 * M * N * K / ms / 1e9);
     }
   }
