@@ -37,21 +37,50 @@ GEMM_DTYPE = 'f32 via bf16x3 split, 6 terms, fp32 accumulate'
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per GEMM launch of the default workload, from the committed --pmc passes
 # (tools/summarize_profile.py traffic; FETCH_SIZE x2 + WRITE_SIZE, separate passes)
-TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r02i_hbm_traffic.json')
+TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')
+SCORING_TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r03_scoring_hbm_traffic.json')
 
 
-def measured_traffic(args):
-    """PMC counters cannot be read from inside the timed run; the figure comes from the
-    committed rocprofv3 --pmc passes over this same command, and only for the workload they
-    were collected on."""
-    if (args.batch_size, args.max_node_count, args.num_operations, args.gnn_width, args.z_dim) != \
-            (512, 100, 1001, None, 10):
+def measured_traffic(args, kernel=None, profile=TRAFFIC_PROFILE):
+    """PMC counters cannot be read from inside the timed run; the figures come from the
+    committed rocprofv3 --pmc passes over this same command (tools/profile_bench.sh), and only
+    for the workload they were collected on.  `kernel=None`: the GEMM family; else the HBM
+    bytes per launch of the kernel whose name starts with `kernel`."""
+    if (args.batch_size, args.max_node_count, args.num_operations, args.gnn_width, args.z_dim,
+            args.score_k, args.score_batch) != (512, 100, 1001, None, 10, 100, 128):
         return None
     try:
-        with open(TRAFFIC_PROFILE) as f:
-            return float(json.load(f)['family_bytes_per_launch'])
+        with open(profile) as f:
+            doc = json.load(f)
+        if kernel is None:
+            return float(doc['family_bytes_per_launch'])
+        hits = [v for k, v in doc['kernels'].items() if k.startswith(kernel)]
+        n = sum(v['launches'] for v in hits)
+        return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hits) / n if n else None
     except (OSError, KeyError, ValueError):
         return None
+
+
+def message_passing_entry(name, summary, tags, elapsed, traffic):
+    """One message-passing kernel against the HBM peak.  `frac` prices the COMPULSORY bytes of a
+    launch (every row in once, every row out once, index and coefficient arrays once: what must
+    cross the HBM interface however good the caches are) and cannot exceed 1; the per-edge model
+    of SURVEY.md section 8d (a neighbour row counted once per in-edge, although the L2 serves
+    most of those gathers) is kept beside it as `per_edge_model`."""
+    c, w, ms = summary[name]
+    compulsory = sum(tag * rec[0] for tag, rec in tags.items() if tag is not None)
+    rate = compulsory / (ms * 1e-3) / 1e9
+    out = {'bound': 'hbm', 'achieved': rate, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': rate / HBM_PEAK_GBS, 'bytes_model': 'compulsory (rows once in, once out)',
+           'per_edge_model': {'achieved': w / (ms * 1e-3) / 1e9,
+                              'ratio_to_peak': w / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              'note': 'SURVEY.md 8d bytes (a row per in-edge); gathers the L2 '
+                                      'serves are counted, so this is not an HBM fraction'},
+           'launches': c, 'avg_ms': ms / c, 'share_of_step': ms * 1e-3 / elapsed,
+           'traffic': traffic, 'traffic_unit': 'PMC bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)'}
+    if traffic:
+        out['traffic_rate_GBs'] = traffic / (ms / c * 1e-3) / 1e9
+    return out
 
 
 def parse_args():
@@ -62,7 +91,14 @@ def parse_args():
     ap.add_argument('--batch-size', type=int, default=512, help='traces per GPU per step')
     ap.add_argument('--max-node-count', type=int, default=100)
     ap.add_argument('--num-operations', type=int, default=1001)
-    ap.add_argument('--pool', type=int, default=2048, help='synthetic traces generated per rank')
+    ap.add_argument('--pool', type=int, default=1 << 20,
+                    help='traces of the HBM-resident store per rank (configs[1]: one million)')
+    ap.add_argument('--unique-traces', type=int, default=8192,
+                    help='traces built by the object-level generator; the store tiles them up to '
+                         '--pool with per-copy latencies (synth.tile_flat)')
+    ap.add_argument('--sweep-batches', type=str, default='64,128',
+                    help='other per-GPU batch sizes timed after the main leg (N=1; "" = skip); '
+                         '64 is the reference default (train.py:73)')
     ap.add_argument('--score-k', type=int, default=100,
                     help='n_z of the scoring leg: BASELINE.json configs[3] scores with K = 100 (0 = skip)')
     ap.add_argument('--score-batch', type=int, default=128)
@@ -70,6 +106,8 @@ def parse_args():
     ap.add_argument('--prior-samples', type=int, default=128,
                     help='traces drawn per call in the prior-sampling leg (N=1 only; 0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scoring-only', action='store_true',
+                    help='run the scoring leg alone and print its object (profiling passes)')
     ap.add_argument('--gnn-width', type=int, default=None, help='per-head GAT width (default 500)')
     ap.add_argument('--z-dim', type=int, default=10, help='z / z2 dimension (train.sh: 10)')
     ap.add_argument('--gemm-shapes', action='store_true', help='per-shape GEMM table on stderr')
@@ -201,15 +239,20 @@ def main():
     from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
     from tracevae_amd.evaluation import eval_step
     from tracevae_amd.model import TraceVAE
-    from tracevae_amd.synth import SyntheticSpec, generate_flat
+    from tracevae_amd.synth import SyntheticSpec, generate_flat, tile_flat
     from tracevae_amd.train import Trainer
 
     V, M, B = args.num_operations, args.max_node_count, args.batch_size
     cfg = make_config(args.gnn_width, args.z_dim)
     spec = SyntheticSpec(num_operations=V, max_spans=M, seed=args.seed)
     # every rank generates its own shard of the synthetic set (seeded by rank)
-    flat, lr = generate_flat(spec, args.pool, seed=args.seed + 1 + rank)
+    unique = min(args.unique_traces, args.pool)
+    flat, lr = generate_flat(spec, unique, seed=args.seed + 1 + rank)
+    copies = max(args.pool // unique, 1)
+    flat = tile_flat(flat, copies, seed=args.seed + 101 + rank)
     store = DeviceTraceStore(flat, lr, V)
+    store_bytes = sum(t.numel() * t.element_size() for t in (
+        store.u, store.v, store.node_type, store.avg_latency, store.min_latency, store.max_latency))
     torch.manual_seed(args.seed)          # identical initial weights on every rank
     vae = TraceVAE(cfg.model, V, max_node_count=M).to(dev)
     for m in vae.modules():
@@ -218,16 +261,19 @@ def main():
     trainer = Trainer(vae, cfg, world_size=world)
     rng = np.random.RandomState(args.seed + rank)
 
-    def train_one():
-        ids = rng.randint(0, len(store), size=B)
+    def train_one(batch=B, check_nan=False):
+        ids = rng.randint(0, len(store), size=batch)
         G = TraceGraphBatch.from_store(store, ids, M)
-        return trainer.step(G, check_nan=False)['loss']
+        return trainer.step(G, check_nan=check_nan)['loss']
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.scoring_only:
+        args.steps = args.warmup = 0
+        args.sweep_batches = ''
     for _ in range(args.warmup):
         train_one()
     barrier()
@@ -239,6 +285,9 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.TIMER.enabled = False
     kernel_summary = ops.TIMER.summary()
+    # per-shape / per-tag tables of the TRAINING leg, taken before any other leg resets the timer
+    train_gemm_tags = ops.TIMER.by_tag('gemm_f32')
+    train_mp_tags = {n: ops.TIMER.by_tag(n) for n in ('gat_aggregate_fwd', 'gat_aggregate_bwd')}
     if args.gemm_shapes and rank == 0:
         rows = sorted(ops.TIMER.by_tag('gemm_f32').items(), key=lambda kv: -kv[1][2])
         for (m, n, k, ta, tb), (cnt, work, ms) in rows:
@@ -249,9 +298,38 @@ def main():
                          device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_vals = torch.stack(losses).cpu().numpy()
+    loss_vals = torch.stack(losses).cpu().numpy() if losses else np.zeros(0)
     if not np.all(np.isfinite(loss_vals)):
         raise RuntimeError(f'non-finite training loss in the timed region: {loss_vals}')
+
+    # ---- the same step as the product's default `Trainer.step` issues it: with the reference's
+    # per-step NaN check (train.py:273, a host sync every step); and other batch sizes
+    def timed(fn, steps):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64,
+                              device=dev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    dt_nan = timed(lambda: train_one(B, True), args.steps)
+    elapsed = max(elapsed, 1e-9)
+    sweep = {}
+    if world == 1 and args.sweep_batches:
+        for b in [int(x) for x in args.sweep_batches.split(',') if x]:
+            for _ in range(3):
+                train_one(b)
+            n_sw = max(args.steps, 20)
+            dt_b = timed(lambda: train_one(b), n_sw)
+            sweep[str(b)] = {'ms_per_step': 1e3 * dt_b / n_sw, 'traces_per_sec': b * n_sw / dt_b}
+        sweep[str(B)] = {'ms_per_step': 1e3 * elapsed / args.steps,
+                         'traces_per_sec': B * args.steps / elapsed}
 
     # ---- scoring leg (not part of `value`; reported next to it): every rank scores its own
     # shard of traces, no communication; whole-job rate over all ranks.
@@ -291,16 +369,18 @@ def main():
             tf = g[1] / (g[2] * 1e-3) / 1e12
             scoring['roofline'] = {
                 'bound': 'mfma', 'kernel': GEMM_KERNEL, 'achieved': tf, 'peak': GEMM_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': tf / GEMM_PEAK_TFLOPS, 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': tf / GEMM_PEAK_TFLOPS,
+                'traffic': measured_traffic(args, None, SCORING_TRAFFIC_PROFILE),
+                'traffic_unit': 'bytes/launch (profiles/r03_scoring_hbm_traffic.json)',
                 'launches': g[0], 'avg_ms': g[2] / max(g[0], 1), 'share_of_step': g[2] * 1e-3 / dt}
             ideal = g[1] / (GEMM_PEAK_TFLOPS * 1e12)
             a = score_kernels.get('gat_aggregate_fwd')
             if a and a[2] > 0:
-                ideal += a[1] / (HBM_PEAK_GBS * 1e9)
-                scoring['gat_aggregate_fwd'] = {
-                    'bound': 'hbm', 'achieved': a[1] / (a[2] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                    'unit': 'GB/s', 'frac': a[1] / (a[2] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    'launches': a[0], 'avg_ms': a[2] / a[0], 'share_of_step': a[2] * 1e-3 / dt}
+                entry = message_passing_entry(
+                    'gat_aggregate_fwd', score_kernels, ops.TIMER.by_tag('gat_aggregate_fwd'), dt,
+                    measured_traffic(args, 'gat_aggregate_fwd_kernel', SCORING_TRAFFIC_PROFILE))
+                ideal += entry['achieved'] * 1e9 * a[2] * 1e-3 / (HBM_PEAK_GBS * 1e9)
+                scoring['gat_aggregate_fwd'] = entry
             scoring['step_roofline'] = {'ideal_ms_per_step': 1e3 * ideal / args.score_steps,
                                         'measured_ms_per_step': 1e3 * dt / args.score_steps,
                                         'frac': ideal / dt}
@@ -338,6 +418,12 @@ def main():
                                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                          'frac': algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
+    if args.scoring_only:
+        if rank == 0:
+            print(json.dumps({'scoring': scoring}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if rank == 0:
         value = B * world * args.steps / elapsed
         g = kernel_summary.get('gemm_f32', (0, 0.0, 0.0))
@@ -354,7 +440,7 @@ def main():
                     'share_of_step': g[2] * 1e-3 / elapsed}
             # the same figure for the shapes that carry the time (the aggregate above also
             # holds the skinny K=40 / N=50 layers and the [512,10] MLP heads)
-            tags = sorted(ops.TIMER.by_tag('gemm_f32').items(), key=lambda kv: -kv[1][2])[:4]
+            tags = sorted(train_gemm_tags.items(), key=lambda kv: -kv[1][2])[:4]
             roof['top_shapes'] = [
                 {'m': t[0], 'n': t[1], 'k': t[2], 'trans_a': t[3], 'trans_b': t[4],
                  'launches_per_step': c / args.steps, 'ms_per_step': ms / args.steps,
@@ -362,23 +448,23 @@ def main():
                  'frac': w / (ms * 1e-3) / 1e12 / GEMM_PEAK_TFLOPS}
                 for t, (c, w, ms) in tags]
         others = {}
+        pmc_names = {'gat_aggregate_fwd': 'gat_aggregate_fwd_kernel',
+                     'gat_aggregate_bwd': 'gat_bwd_fused_kernel'}
         for name in ('gat_aggregate_fwd', 'gat_aggregate_bwd'):
             if name in kernel_summary and kernel_summary[name][2] > 0:
-                c, w, ms = kernel_summary[name]
-                others[name] = {'bound': 'hbm', 'achieved': w / (ms * 1e-3) / 1e9,
-                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                'frac': w / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'launches': c,
-                                'avg_ms': ms / c, 'share_of_step': ms * 1e-3 / elapsed}
+                others[name] = message_passing_entry(
+                    name, kernel_summary, train_mp_tags[name], elapsed,
+                    measured_traffic(args, pmc_names[name]))
         # step-level figure of SURVEY.md section 8d: sum over the attributed kernels of their
         # ideal time (flops / MFMA peak, or algorithmic bytes / HBM peak) over the measured step;
         # kernels without a work model count as zero ideal time, so this is a lower bound
         ideal_s = attributed_ms = 0.0
-        for name, peak in (('gemm_f32', GEMM_PEAK_TFLOPS * 1e12),
-                           ('gat_aggregate_fwd', HBM_PEAK_GBS * 1e9),
-                           ('gat_aggregate_bwd', HBM_PEAK_GBS * 1e9)):
-            if name in kernel_summary:
-                ideal_s += kernel_summary[name][1] / peak
-                attributed_ms += kernel_summary[name][2]
+        if 'gemm_f32' in kernel_summary:
+            ideal_s += kernel_summary['gemm_f32'][1] / (GEMM_PEAK_TFLOPS * 1e12)
+            attributed_ms += kernel_summary['gemm_f32'][2]
+        for name, entry in others.items():        # compulsory bytes at the HBM peak
+            ideal_s += entry['achieved'] * entry['avg_ms'] * entry['launches'] * 1e-3 / HBM_PEAK_GBS
+            attributed_ms += kernel_summary[name][2]
         # (the same sum with the GEMM priced at the fp32 matrix peak of 157.3 TFLOP/s, the bound
         # of the kernel it replaced, is kept beside it so that rounds can be compared)
         ideal_f32 = ideal_s
@@ -389,20 +475,32 @@ def main():
                      'frac': ideal_s / elapsed,
                      'frac_with_gemm_at_fp32_matrix_peak': ideal_f32 / elapsed,
                      'attributed_share_of_step': attributed_ms * 1e-3 / elapsed,
-                     'covers': 'gemm_f32 against bf16 MFMA peak / 6, gat_aggregate_fwd/bwd against '
-                               'HBM; every other kernel counts as zero ideal time (lower bound). '
+                     'covers': 'gemm_f32 against bf16 MFMA peak / 6, gat_aggregate_fwd/bwd '
+                               '(compulsory bytes) against HBM; every other kernel counts as zero '
+                               'ideal time (lower bound). '
                                'The step is compute-dominated: the HBM figures refer to the '
                                'message-passing kernels only'}
         line = {
             'metric': 'train_step_traces_per_sec', 'value': value, 'unit': 'traces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'ms_per_step_with_nan_check': 1e3 * dt_nan / args.steps,
+            'nan_check': 'value / ms_per_step: the loss of every step is checked after the timed '
+                         'region (one sync at the end); ms_per_step_with_nan_check: the same '
+                         'steps with the host sync of train.py:273 in every step (Trainer.step '
+                         'default)',
+            'batch_sweep': sweep or None,
+            'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': GEMM_DTYPE, 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[1]: synthetic traces <=100 spans, '
                                    '1k-op vocab, default TraceVAE dims (train.sh flags), '
                                    'MAX_NODE_COUNT=100, training step',
                        'batch_per_gpu': B, 'global_batch': B * world, 'max_node_count': M,
-                       'num_operations': V, 'pool_traces_per_gpu': args.pool,
+                       'num_operations': V, 'store_traces_per_gpu': len(store),
+                       'store_bytes_per_gpu': store_bytes,
+                       'store': f'{len(store)} traces resident in HBM = {copies} copies of '
+                                f'{unique} generated traces with per-copy latencies; batches '
+                                f'are drawn uniformly from the whole store',
                        'parallelism': f'dp{world}'},
             'roofline': roof, 'step_roofline': step_roof, 'other_kernels': others,
             'scoring': scoring,

@@ -457,7 +457,8 @@ int tv_realnvp_supported(int dim, int hidden);
 /* Data-dependent initialisation of the ActNorm layers on the first batch (tensorkit ActNorm;
  * the `initialize()` pass of train.py:188-199): level by level bias = -mean, pre_scale =
  * -log(max(std, 1e-6)) of the level's input over the rows (biased variance), written into
- * params[l*9 + 0] and params[l*9 + 1]; the other tensors are only read.  1 <= rows <= 1024. */
+ * params[l*9 + 0] and params[l*9 + 1]; the other tensors are only read.  1 <= rows <= 2^24 (up to
+ * 1024 rows a lane holds its row through the levels; larger batches recompute the level inputs). */
 int tv_realnvp_actnorm_init(int64_t rows, int levels, int dim, int hidden, float slope,
                             const float *z, float *const *params, void *stream);
 int64_t tv_realnvp_workspace_floats(int64_t rows, int levels, int dim, int hidden);

@@ -104,6 +104,18 @@ def rel_err(a, b):
     return float((a - b).abs().max() / denom)
 
 
+def elem_rel_err(a, b, floor):
+    """Per-ELEMENT relative error, max_i |a_i - b_i| / max(|b_i|, floor): the form north_star's
+    "per-trace anomaly scores within 1e-4 relative" asks for.  `floor` is the magnitude below
+    which an element is held to an absolute error of tol * floor instead (a log-probability
+    that happens to pass through zero has no meaningful relative error)."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu().reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).cpu().reshape(-1)
+    if a.numel() == 0:
+        return 0.0
+    return float(((a - b).abs() / b.abs().clamp(min=floor)).max())
+
+
 def golden_sample_flat():
     """The 17 traces of the reference's `sample_dataset`, as the reference's own
     `graph_vectors()` produced them (tests/golden/sample_dataset_vectors.json), as one

@@ -40,13 +40,17 @@ def _shard(rank):
     return TraceGraphBatch.from_store(store, ids, M), eps
 
 
-def _dp_worker(rank, world, port, tmp):
+def _dp_worker(rank, world, port, tmp, backend='gloo'):
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    device = torch.device('cuda', 0)
+    # gloo: both ranks on the one GPU; nccl (= RCCL): one GPU per rank, communicator bound to it
+    device = torch.device('cuda', rank if backend == 'nccl' else 0)
     torch.cuda.set_device(device)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     trainer = _trainer(device, world)
     G, eps = _shard(rank)
     out = trainer.step(G, eps=eps)
@@ -56,10 +60,27 @@ def _dp_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_averaged_gradients(device, tmp_path):
+def _spawn_with_deadline(fn, args, world, seconds=240):
+    import time
     import torch.multiprocessing as mp
-    world, port = 2, 31000 + os.getpid() % 2000
-    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ctx = mp.spawn(fn, args=args, nprocs=world, join=False)
+    deadline = time.time() + seconds
+    while not ctx.join(timeout=1.0):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+            pytest.fail('a rank was still blocked at the deadline (unmatched collective?)')
+
+
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_two_rank_step_equals_averaged_gradients(device, tmp_path, backend):
+    """`backend='nccl'` is the product's own exchange (RCCL, one GPU per rank); it needs two
+    visible GPUs and is skipped on the one-GPU test box, where gloo rehearses the control flow."""
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('RCCL with two ranks needs two GPUs')
+    world, port = 2, 31000 + os.getpid() % 2000 + (17 if backend == 'nccl' else 0)
+    _spawn_with_deadline(_dp_worker, (world, port, str(tmp_path), backend), world)
     got = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
 
     # the same in one process: per-shard gradients (L2 term included), their mean, one update
@@ -174,3 +195,87 @@ def test_two_rank_fit_with_odd_batch_count_across_the_phase_switch(device, tmp_p
     assert any('Start to train latency_vae' in line for line in r[0]['log'])
     with open(out / 'result' / 'test-anomaly' / 'final.json') as f:
         assert json.load(f).keys() >= {'auc', 'best_fscore', 'test_loss'}
+
+
+# ---------------------------------------------------------------------------------------
+# the RCCL code path itself, executed with the one rank a one-GPU box can hold
+# ---------------------------------------------------------------------------------------
+def _rccl_single_rank_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+    from tracevae_amd.train import NANLossError, _uses_device_collectives
+    assert _uses_device_collectives(None)
+    out = {}
+    for phase2 in (False, True):
+        # reference run: no collective at all
+        ref = _trainer(device, 1)
+        ref.set_phase(phase2)
+        G, eps = _shard(0)
+        ref_out = ref.step(G, eps=eps)
+        # the same step through the RCCL all-reduce of [gradient range | NaN flag]
+        tr = _trainer(device, 1)
+        tr.exchange_single_rank = True
+        tr.set_phase(phase2)
+        sizes = []
+        real = dist.all_reduce
+
+        def spy(t, *a, **k):
+            sizes.append((t.is_cuda, t.numel(), t.data_ptr()))
+            return real(t, *a, **k)
+        dist.all_reduce = spy
+        try:
+            got = tr.step(G, eps=eps)
+        finally:
+            dist.all_reduce = real
+        f = tr.flat
+        assert len(sizes) == 1 and sizes[0][0], sizes                  # ONE device collective
+        assert sizes[0][1] == f.flag_index + 1 - tr.optimizer.start     # gradients + flag slot
+        assert sizes[0][2] == f.bucket.data_ptr() + 4 * tr.optimizer.start
+        assert (tr.optimizer.start > 0) == phase2                       # phase 2: the suffix
+        assert float(f.bucket[f.flag_index]) == 0.0
+        out[phase2] = (torch.equal(tr.flat.flat, ref.flat.flat),
+                       torch.equal(got['loss'], ref_out['loss']))
+    # a NaN loss travels in the flag slot and raises after the collective
+    tr = _trainer(device, 1)
+    tr.exchange_single_rank = True
+    G, eps = _shard(0)
+    with torch.no_grad():
+        tr.flat.flat[:8] = float('nan')
+    try:
+        tr.step(G, eps=eps)
+        out['nan'] = False
+    except NANLossError:
+        out['nan'] = float(tr.flat.bucket[tr.flat.flag_index]) == 1.0
+    # the small collectives around the step: model broadcast, BatchNorm averaging, scalars
+    from tracevae_amd.train import all_reduce_sum, average_batch_norm_buffers, broadcast_model
+    tr = _trainer(device, 1)
+    before = tr.flat.flat.clone()
+    broadcast_model(tr)
+    average_batch_norm_buffers(tr.vae, 2)        # "two ranks": halves every float buffer
+    acc = torch.ones(2, dtype=torch.float64, device=device)
+    all_reduce_sum(acc)
+    out['aux'] = torch.equal(before, tr.flat.flat) and bool((acc == 1).all()) and all(
+        torch.allclose(b, torch.full_like(b, 0.5)) for n, b in tr.vae.named_buffers()
+        if n.endswith('running_var'))
+    torch.save(out, os.path.join(tmp, 'rccl1.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_code_path_with_one_rank(device, tmp_path):
+    """The `nccl` (= RCCL) branch of the exchange cannot run with two ranks on a one-GPU box;
+    with ONE rank it still executes everything that is RCCL-specific: the communicator bound to
+    the device (`device_id=`), the in-place device all-reduce over the slice
+    [gradients of the trained range | NaN flag] of the flat bucket, its phase-2 suffix form, the
+    NaN vote, the model broadcast and the BatchNorm-buffer averaging.  A sum over one rank
+    changes nothing, so the step must be bit-equal to the step without a collective.  (Run in
+    a child process: a process group cannot be re-initialised inside the test process.)"""
+    port = 33000 + os.getpid() % 2000
+    _spawn_with_deadline(_rccl_single_rank_worker, (1, port, str(tmp_path)), 1, seconds=180)
+    out = torch.load(tmp_path / 'rccl1.pt', weights_only=False)
+    assert out[False] == (True, True) and out[True] == (True, True), out
+    assert out['nan'] and out['aux'], out

@@ -280,11 +280,13 @@ extern "C" int tv_batch_build(
   a.graph_id = graph_id; a.lat_row_weight = lat_row_weight; a.status = status;
   const size_t lds_bytes = sizeof(int32_t) * (size_t)(BB_LDS_INTS_PER_NODE * M + 1);
   if (lds_bytes > 64 * 1024) {
-    static bool raised = false;          // per process
-    if (!raised) {
+    static bool raised[64] = {};         // per device: the attribute belongs to the device's code object
+    int device = 0;
+    TV_HIP(hipGetDevice(&device));
+    if (!raised[device & 63]) {
       TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&batch_build_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
+      raised[device & 63] = true;
     }
   }
   // long traces get four waves per trace, short ones one

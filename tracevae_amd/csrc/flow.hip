@@ -299,6 +299,74 @@ __global__ __launch_bounds__(1024) void flow_actnorm_init_kernel(int rows, int l
   }
 }
 
+// The same initialisation for a batch of MORE than 1024 rows (train.init_batch_size above 1024,
+// or a first log_prob call on K*B rows of a model that has not been initialised): one workgroup
+// again - the levels are sequential and the statistics are over the whole batch - with every
+// lane striding over rows t, t + 1024, ...  A lane cannot keep all its rows in registers, so
+// the input of level l is recomputed from z through the (by then initialised) levels 0..l-1 for
+// each of the two passes (mean, then squared deviations, float64 as above).  The chunk loops
+// have the same trip count in every lane, so the barriers inside stage_level's callers line up.
+// Work: levels^2 * rows level evaluations, a few milliseconds at 10^5 rows, once per model.
+template <int D, int H>
+__global__ __launch_bounds__(1024) void flow_actnorm_init_strided_kernel(int64_t rows, int levels,
+                                                                         float slope,
+                                                                         const float *__restrict__ z,
+                                                                         FlowPtrs fp, FlowGradPtrs out) {
+  using L = LdsW<D, H>;
+  __shared__ __align__(16) float s_w[L::SIZE];
+  __shared__ double s_red[16][D];
+  __shared__ double s_mean[D];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t chunks = (rows + 1023) / 1024;
+  for (int l = 0; l < levels; ++l) {
+    for (int pass = 0; pass < 2; ++pass) {
+      double acc[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc[j] = 0.0;
+      for (int64_t c = 0; c < chunks; ++c) {
+        const int64_t r = c * 1024 + t;
+        const bool valid = r < rows;
+        float x[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = valid ? z[r * D + j] : 0.f;
+        for (int l2 = 0; l2 < l; ++l2) {
+          __syncthreads();
+          stage_level<D, H, 1024>(fp.p[l2], s_w, t);      // reads the values written below
+          __syncthreads();
+          level_forward<D, H>(s_w, slope, x);
+        }
+        if (valid) {
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const double d = pass == 0 ? (double)x[j] : (double)x[j] - s_mean[j];
+            acc[j] += pass == 0 ? d : d * d;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const double v = tv_wave_sum_d(acc[j]);
+        if (lane == 0) s_red[wave][j] = v;
+      }
+      __syncthreads();
+      if (t < D) {
+        double m = 0.0;
+        for (int w = 0; w < 16; ++w) m += s_red[w][t];
+        if (pass == 0) {
+          s_mean[t] = m / (double)rows;
+        } else {
+          const float sd = (float)sqrt(m / (double)rows);
+          out.g[l][0][t] = (float)(-s_mean[t]);
+          out.g[l][1][t] = -logf(fmaxf(sd, 1e-6f));
+        }
+      }
+      __threadfence();          // the level's bias / pre_scale are read back from memory above
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 constexpr int RS = 65;   // LDS row stride of the staging arrays (64 rows + 1: conflict-free)
 
@@ -541,11 +609,13 @@ int run_bwd(int64_t rows, int levels, float slope, const float *z, const FlowPtr
   const int64_t lds = bwd_lds_bytes<D, H>(levels);
   TV_REQUIRE(lds <= 160 * 1024, "tv_realnvp_logprob_bwd: %lld bytes of LDS needed", (long long)lds);
   if (lds > 64 * 1024) {
-    static bool raised = false;          // per process and instantiation
-    if (!raised) {
+    static bool raised[64] = {};         // per device and instantiation
+    int device = 0;
+    TV_HIP(hipGetDevice(&device));
+    if (!raised[device & 63]) {
       TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&flow_bwd_kernel<D, H>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
+      raised[device & 63] = true;
     }
   }
   if (nblk > 0) {
@@ -563,8 +633,12 @@ int run_bwd(int64_t rows, int levels, float slope, const float *z, const FlowPtr
 template <int D, int H>
 int run_actnorm_init(int64_t rows, int levels, float slope, const float *z, const FlowPtrs &fp,
                      const FlowGradPtrs &out, hipStream_t s) {
-  hipLaunchKernelGGL((flow_actnorm_init_kernel<D, H>), dim3(1), dim3(1024), 0, s, (int)rows, levels,
-                     slope, z, fp, out);
+  if (rows <= 1024)
+    hipLaunchKernelGGL((flow_actnorm_init_kernel<D, H>), dim3(1), dim3(1024), 0, s, (int)rows, levels,
+                       slope, z, fp, out);
+  else
+    hipLaunchKernelGGL((flow_actnorm_init_strided_kernel<D, H>), dim3(1), dim3(1024), 0, s, rows,
+                       levels, slope, z, fp, out);
   TV_LAUNCH_CHECK("tv_realnvp_actnorm_init");
   return TV_OK;
 }
@@ -619,8 +693,8 @@ extern "C" int tv_realnvp_logprob_bwd(int64_t rows, int levels, int dim, int hid
 extern "C" int tv_realnvp_actnorm_init(int64_t rows, int levels, int dim, int hidden, float slope,
                                        const float *z, float *const *params, void *stream) {
   if (int rc = check_dims("tv_realnvp_actnorm_init", rows, levels, dim, hidden)) return rc;
-  TV_REQUIRE(rows >= 1 && rows <= 1024,
-             "tv_realnvp_actnorm_init: the initialisation batch must hold 1..1024 rows, got %lld",
+  TV_REQUIRE(rows >= 1 && rows <= (1 << 24),
+             "tv_realnvp_actnorm_init: the initialisation batch must hold 1..2^24 rows, got %lld",
              (long long)rows);
   TV_REQUIRE(z, "tv_realnvp_actnorm_init: null pointer");
   FlowPtrs fp{};

@@ -145,7 +145,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
     (`tv_gemm_f32_act`)."""
     a, b = _rows(a, 'a'), _rows(b, 'b')
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
-    if not trans_a and k % 4 and a.stride(0) % 4 == 0 and a.stride(0) >= k + 3:
+    if not trans_a and k % 4 and a.stride(0) % 4 == 0 and a.stride(0) >= (k + 3) // 4 * 4:
         # the library reads such rows 16 bytes at a time, up to 3 floats past k (tracevae_hip.h):
         # fine for a column slice of a wider buffer, not for a view whose storage ends with the
         # last element
@@ -429,7 +429,11 @@ class _GATConv(Function):
         # algorithmic bytes: ft gathered once per in-edge + out written once (+ scores/indices)
         work = 4.0 * hf * (graph.num_edges + graph.num_rows) * n_rep \
             + (8.0 * heads * (graph.num_edges + graph.num_rows) + 8.0 * graph.num_edges) * n_rep
-        with TIMER.region('gat_aggregate_fwd', work):
+        # compulsory bytes (the timer's tag): every [ft | el | er] row in once, every output row
+        # out once, the CSC arrays once, the attention coefficients out once when they are kept
+        compulsory = 4.0 * (ft.stride(0) + hf) * rows + 8.0 * (graph.num_edges + graph.num_rows) \
+            + (4.0 * heads * graph.num_edges if need_grad else 0.0)
+        with TIMER.region('gat_aggregate_fwd', work, compulsory):
             hip.call('tv_gat_aggregate_fwd', graph.num_rows, n_rep, heads, feats,
                      hip.ptr(graph.indptr), hip.ptr(graph.indices), hip.ptr(ft), hip.ptr_rows(el),
                      hip.ptr_rows(er), hip.ptr(bias), hip.ptr(out), hip.ptr(alpha), hip.ptr(stats),
@@ -474,7 +478,10 @@ class _GATConv(Function):
         # in-edge, ft row read, dft written)
         hf = heads * feats
         work = 4.0 * hf * (2 * g.num_edges + 3 * g.num_rows)
-        with TIMER.region('gat_aggregate_bwd', work):
+        # compulsory bytes: dout and ft rows in once, dft rows out once, coefficients and CSC / rev
+        compulsory = 4.0 * (hf + 2 * ft.stride(0)) * g.num_rows + 4.0 * heads * g.num_edges \
+            + 8.0 * (2 * g.num_edges + g.num_rows)
+        with TIMER.region('gat_aggregate_bwd', work, compulsory):
             hip.call('tv_gat_aggregate_bwd', g.num_rows, 1, heads, feats, g.num_edges,
                      hip.ptr(g.indptr), hip.ptr(g.indices), hip.ptr(g.rev), hip.ptr(ft),
                      hip.ptr_rows(el), hip.ptr_rows(er), hip.ptr(al), hip.ptr(ar), hip.ptr(alpha),

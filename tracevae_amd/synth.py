@@ -17,7 +17,8 @@ import numpy as np
 from .data import (FlatTraces, TraceGraph, TraceGraphLatencyRangeFile, TraceGraphNode,
                    TraceGraphNodeFeatures, flatten_trace_graphs)
 
-__all__ = ['SyntheticSpec', 'make_latency_range', 'generate_trace_graphs', 'generate_flat']
+__all__ = ['SyntheticSpec', 'make_latency_range', 'generate_trace_graphs', 'generate_flat',
+           'tile_flat']
 
 SIGMA = 0.5
 
@@ -97,3 +98,25 @@ def generate_flat(spec: SyntheticSpec, count: int, seed: Optional[int] = None,
                   anomaly_ratio: float = 0.0) -> Tuple[FlatTraces, TraceGraphLatencyRangeFile]:
     graphs = generate_trace_graphs(spec, count, seed=seed, anomaly_ratio=anomaly_ratio)
     return flatten_trace_graphs(graphs), make_latency_range(spec)
+
+
+def tile_flat(flat: FlatTraces, copies: int, seed: int = 0, jitter: float = 0.1) -> FlatTraces:
+    """A data set of `copies * len(flat)` traces for store-sized runs (BASELINE.json configs[1]:
+    one million traces resident in HBM): the object-level generator above builds a trace in
+    ~0.4 ms of Python, so a million of them would take minutes; here the topologies and operation
+    ids of `flat` repeat `copies` times and every copy draws its own latencies around the
+    originals (x exp(jitter * N(0,1)) per node, min <= avg <= max kept).  Copy 0 is `flat`."""
+    if copies <= 1:
+        return flat
+    rng = np.random.default_rng(seed)
+    n, t = int(flat.node_offsets[-1]), len(flat)
+    off = (flat.node_offsets[None, :-1] + n * np.arange(copies, dtype=np.int64)[:, None]).reshape(-1)
+    off = np.concatenate([off, [n * copies]]).astype(np.int64)
+    scale = np.exp(jitter * rng.standard_normal(n * copies)).astype(np.float32)
+    scale[:n] = 1.0
+    rep = lambda a: np.tile(a, copies)
+    return FlatTraces(
+        node_offsets=off, u=rep(flat.u), v=rep(flat.v), node_type=rep(flat.node_type),
+        avg_latency=rep(flat.avg_latency) * scale, max_latency=rep(flat.max_latency) * scale,
+        min_latency=rep(flat.min_latency) * scale,
+        labels=None if flat.labels is None else rep(flat.labels))

@@ -228,6 +228,10 @@ class Trainer(object):
         self.world_size = world_size if world_size is not None else (
             dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1)
         self.epoch = 1
+        # run the collective of `exchange` even with ONE rank (a sum over one rank changes
+        # nothing): lets a one-GPU box execute the RCCL code path itself - communicator bound to
+        # the device, all-reduce of [gradient range | NaN flag] in device memory
+        self.exchange_single_rank = False
         self.set_phase(latency_only)
 
     # -- phases ------------------------------------------------------------------------
@@ -315,7 +319,7 @@ class Trainer(object):
         return {k: v.detach() for k, v in out.items() if k != 'chain'}
 
     def loss_is_nan(self, loss: torch.Tensor) -> bool:
-        if self.world_size > 1:
+        if self.world_size > 1 or self.exchange_single_rank:
             # the all-reduced flag: the number of ranks whose loss was NaN
             return float(self.flat.bucket[self.flat.flag_index].item()) != 0.0
         return math.isnan(float(loss.item()))
@@ -323,7 +327,7 @@ class Trainer(object):
     def exchange(self, loss: Optional[torch.Tensor] = None) -> None:
         """One collective over [gradients of the trained range | NaN flag]: sum over ranks,
         gradients divided by the world size."""
-        if self.world_size <= 1:
+        if self.world_size <= 1 and not self.exchange_single_rank:
             return
         f = self.flat
         flag = f.bucket[f.flag_index:f.flag_index + 1]
@@ -582,12 +586,29 @@ def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: 
         if config.seed is not None:
             torch.manual_seed(config.seed + rank)
 
+    # train.py:443-448: `mltk.callbacks.EarlyStopping(checkpoint, metric_name='val_loss')` keeps
+    # the state of the epoch with the smallest validation loss and restores it when the train
+    # loop ends, before the final model is saved and scored (it does not cut the run short: no
+    # patience is given).  Active only together with `val_epoch_freq`, like the reference.
+    # mltk is not in the container: semantics from its API, parity unpinned.  The validation
+    # loss is the all-reduced one, so every rank keeps and restores the same epoch.
+    early = {'best': math.inf, 'epoch': None, 'state': None} \
+        if (tc.val_epoch_freq and tc.use_early_stopping) else None
+
     def epoch_end(epoch, mean_loss, seconds):
         average_batch_norm_buffers(vae, world_size, process_group)
         msg = f'epoch {epoch}/{tc.max_epoch}: loss {mean_loss:.6g} ({seconds:.2f}s)'
         if tc.val_epoch_freq and epoch % tc.val_epoch_freq == 0:
             result['val_loss'] = validation_loss()
             msg += f' val_loss {result["val_loss"]:.6g}'
+            if early is not None and result['val_loss'] < early['best']:
+                early.update(best=result['val_loss'], epoch=epoch,
+                             state={k: v.detach().clone() for k, v in vae.state_dict().items()})
+                if rank == 0:
+                    os.makedirs(os.path.join(out_dir, 'early-stopping'), exist_ok=True)
+                    torch.save({k: v.cpu() for k, v in early['state'].items()},
+                               os.path.join(out_dir, 'early-stopping', 'best.pt'))
+                msg += ' (best so far)'
         log(msg)
         if tc.test_epoch_freq and epoch % tc.test_epoch_freq == 0:
             r = evaluate(tc.test_n_z, str(epoch))
@@ -598,6 +619,12 @@ def fit(config: ExpConfig, stores: Dict[str, DeviceTraceStore], num_operations: 
 
     pretrain = tc.struct_pretrain_epochs if config.model.arch == 'default' else None
     run_training(trainer, train_stream, tc, pretrain, epoch_end, log)
+    if early is not None and early['state'] is not None:
+        log(f'early stopping: restoring the parameters of epoch {early["epoch"]} '
+            f'(val_loss {early["best"]:.6g})')
+        with torch.no_grad():
+            vae.load_state_dict(early['state'])     # copies into the flat buffer's views
+        result['early_stopping_epoch'] = early['epoch']
     vae.eval()
     if rank == 0:
         save_model(vae, config, out_dir, name='final')
@@ -613,14 +640,22 @@ MAX_NAN_RESTARTS = 10
 
 
 def run_with_nan_restart(job, out_dir: str, rank: int = 0, world_size: int = 1,
-                         process_group=None, log=None):
+                         process_group=None, log=None, config: Optional[ExpConfig] = None):
     """The outer loop of train.py:510-531: when the loss turns NaN during epoch 1 the whole
     experiment starts over (a fresh model, up to 10 times), with the output directories of the
     failed try removed; a NaN in a later epoch, or an eleventh one, propagates.  `job()` runs
     one try.  Under data parallelism `NANLossError` is raised on every rank in the same step
-    (`Trainer.step`), so all ranks restart together."""
+    (`Trainer.step`), so all ranks restart together.
+
+    The reference re-runs `main()` with the same `--seed`, and on its engine (non-deterministic
+    atomics, a fresh CUDA RNG stream) the retry takes another trajectory.  Here every kernel
+    sums in a fixed order, so a retry from the same seed would reach the same NaN ten times:
+    with `config` given, try r runs at `seed + r` (the same on every rank).  `result/` is
+    wiped too, which the reference leaves in place (train.py:525): a failed try's per-epoch
+    test results would otherwise sit beside the successful run's."""
     import shutil
     retrial = 0
+    base_seed = config.seed if config is not None else None
     while True:
         try:
             return job()
@@ -636,6 +671,8 @@ def run_with_nan_restart(job, out_dir: str, rank: int = 0, world_size: int = 1,
                     path = os.path.join(out_dir, name)
                     if os.path.isdir(path):
                         shutil.rmtree(path)
+            if base_seed is not None:
+                config.seed = base_seed + retrial
             if world_size > 1:
                 dist.barrier(group=process_group)
 
@@ -684,7 +721,8 @@ def main(argv=None) -> int:
               'val': DeviceTraceStore(sets['val'], latency_range, v),
               'test': DeviceTraceStore(concat_flat(sets[n] for n in TEST_SETS), latency_range, v)}
     result = run_with_nan_restart(
-        lambda: fit(config, stores, v, out_dir, rank=rank, world_size=world), out_dir, rank, world)
+        lambda: fit(config, stores, v, out_dir, rank=rank, world_size=world), out_dir, rank, world,
+        config=config)
     if rank == 0:
         print(json.dumps({k: val for k, val in result.items() if not k.startswith('_')}, indent=1))
     if world > 1:
