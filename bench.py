@@ -27,13 +27,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The GEMM multiplies fp32 operands as three bf16 pieces each, six bf16 partial products per
-# algorithmic product, fp32 accumulation (csrc/gemm_f32.hip).  Its matrix-core ceiling in
-# algorithmic (2*M*N*K) flops is the dense bf16 peak of MI355X_MICROARCH.md over six.
-BF16_MFMA_PEAK_TFLOPS = 2500.0
-GEMM_KERNEL = 'gemm_kernel / gemm_wide_kernel / gemm_kmajor_wide_kernel'
-GEMM_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
-GEMM_DTYPE = 'f32 via bf16x3 split, 6 terms, fp32 accumulate'
+# The GEMM multiplies fp32 operands on the 16-bit matrix cores (csrc/gemm_f32.hip): the layer
+# products and weight gradients (forms 1 / 2: the wide kernels, which carry the time) as two fp16
+# pieces per element and THREE partial products per algorithmic product, every other shape
+# (form 0) as three bf16 pieces and SIX partial products; fp32 accumulation either way.  The
+# matrix-core ceiling in algorithmic (2*M*N*K) flops is the dense 16-bit peak of
+# MI355X_MICROARCH.md (2500 TFLOP/s for fp16 and bf16 alike) over the number of partial products.
+MFMA16_PEAK_TFLOPS = 2500.0
+GEMM_KERNEL = 'gemm_wide_h_kernel / gemm_kmajor_wide_h_kernel'
+GEMM_PEAK_TFLOPS = MFMA16_PEAK_TFLOPS / 3.0
+GEMM_KERNEL_OTHER = 'gemm_kernel'
+GEMM_PEAK_OTHER_TFLOPS = MFMA16_PEAK_TFLOPS / 6.0
+GEMM_DTYPE = ('f32 in / f32 out; wide GEMM forms: fp16x2 split (x0 + 2^-11 x1, power-of-two operand '
+              'scale), 3 terms, fp32 accumulate; other GEMM shapes: bf16x3 split, 6 terms')
+
+
+def form_peak(form):
+    return GEMM_PEAK_TFLOPS if form in (1, 2) else GEMM_PEAK_OTHER_TFLOPS
+
+
+def gemm_roofline(tags, elapsed, traffic, traffic_unit, steps):
+    """The GEMM family from the per-(shape, form) timer table: the dominant kernels (the fp16
+    forms) against their peak, the bf16 form beside them, and the ideal time of all of it.
+    The timed region of a product includes its own preparation passes (max |operand|, split of
+    B, tail / split-K reductions)."""
+    by_form = {}
+    for tag, (c, w, ms) in tags.items():
+        rec = by_form.setdefault(1 if tag[5] in (1, 2) else 0, [0, 0.0, 0.0])
+        rec[0] += c; rec[1] += w; rec[2] += ms
+    ideal_s = sum(w / (form_peak(f) * 1e12) for f, (c, w, ms) in by_form.items())
+    total_ms = sum(ms for c, w, ms in by_form.values())
+    total_w = sum(w for c, w, ms in by_form.values())
+    if total_ms <= 0:
+        return None, 0.0, 0.0
+    dom = 1 if 1 in by_form else 0
+    c, w, ms = by_form[dom]
+    tf = w / (ms * 1e-3) / 1e12
+    roof = {'bound': 'mfma', 'kernel': GEMM_KERNEL if dom else GEMM_KERNEL_OTHER, 'achieved': tf,
+            'peak': form_peak(dom), 'unit': 'TFLOP/s',
+            'peak_is': 'dense 16-bit MFMA peak (2500 TFLOP/s) / partial products per algorithmic '
+                       'product (3 on the fp16 forms, 6 on the bf16 form); achieved counts '
+                       'algorithmic 2*M*N*K flops over the whole library call (operand-maximum, '
+                       'B-split and reduction passes included)',
+            'frac': tf / form_peak(dom), 'traffic': traffic, 'traffic_unit': traffic_unit,
+            'launches': c, 'avg_ms': ms / max(c, 1), 'share_of_step': ms * 1e-3 / elapsed,
+            'all_gemm': {'achieved': total_w / (total_ms * 1e-3) / 1e12, 'launches': sum(
+                             v[0] for v in by_form.values()),
+                         'share_of_step': total_ms * 1e-3 / elapsed,
+                         'frac_of_ideal': ideal_s / (total_ms * 1e-3)}}
+    if dom and 0 in by_form:
+        c0, w0, ms0 = by_form[0]
+        roof['bf16_form'] = {'kernel': GEMM_KERNEL_OTHER, 'achieved': w0 / (ms0 * 1e-3) / 1e12,
+                             'peak': GEMM_PEAK_OTHER_TFLOPS,
+                             'frac': w0 / (ms0 * 1e-3) / 1e12 / GEMM_PEAK_OTHER_TFLOPS,
+                             'launches': c0, 'share_of_step': ms0 * 1e-3 / elapsed}
+    top = sorted(tags.items(), key=lambda kv: -kv[1][2])[:4]
+    roof['top_shapes'] = [
+        {'m': t[0], 'n': t[1], 'k': t[2], 'trans_a': t[3], 'trans_b': t[4], 'form': t[5],
+         'launches_per_step': c / steps, 'ms_per_step': ms / steps,
+         'achieved': w / (ms * 1e-3) / 1e12, 'frac': w / (ms * 1e-3) / 1e12 / form_peak(t[5])}
+        for t, (c, w, ms) in top]
+    return roof, ideal_s, total_ms
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per GEMM launch of the default workload, from the committed --pmc passes
 # (tools/summarize_profile.py traffic; FETCH_SIZE x2 + WRITE_SIZE, separate passes)
@@ -290,8 +344,8 @@ def main():
     train_mp_tags = {n: ops.TIMER.by_tag(n) for n in ('gat_aggregate_fwd', 'gat_aggregate_bwd')}
     if args.gemm_shapes and rank == 0:
         rows = sorted(ops.TIMER.by_tag('gemm_f32').items(), key=lambda kv: -kv[1][2])
-        for (m, n, k, ta, tb), (cnt, work, ms) in rows:
-            print(f'gemm m={m:7d} n={n:5d} k={k:7d} ta={int(ta)} tb={int(tb)}  x{cnt / args.steps:5.1f}/step '
+        for (m, n, k, ta, tb, form), (cnt, work, ms) in rows:
+            print(f'gemm m={m:7d} n={n:5d} k={k:7d} ta={int(ta)} tb={int(tb)} form={form}  x{cnt / args.steps:5.1f}/step '
                   f'{ms / args.steps:7.3f} ms/step  {work / ms / 1e9:6.1f} TF', file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
@@ -364,16 +418,11 @@ def main():
                    'ms_per_step': 1e3 * dt / args.score_steps,
                    'workload': f'BASELINE.json configs[3]: K={K}-sample NLL scoring, {SB} traces '
                                f'per call per GPU, decoders on K*B*M = {K * SB * M} rows'}
-        g = score_kernels.get('gemm_f32', (0, 0.0, 0.0))
-        if g[2] > 0:
-            tf = g[1] / (g[2] * 1e-3) / 1e12
-            scoring['roofline'] = {
-                'bound': 'mfma', 'kernel': GEMM_KERNEL, 'achieved': tf, 'peak': GEMM_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': tf / GEMM_PEAK_TFLOPS,
-                'traffic': measured_traffic(args, None, SCORING_TRAFFIC_PROFILE),
-                'traffic_unit': 'bytes/launch (profiles/r03_scoring_hbm_traffic.json)',
-                'launches': g[0], 'avg_ms': g[2] / max(g[0], 1), 'share_of_step': g[2] * 1e-3 / dt}
-            ideal = g[1] / (GEMM_PEAK_TFLOPS * 1e12)
+        sroof, ideal, _ = gemm_roofline(
+            ops.TIMER.by_tag('gemm_f32'), dt, measured_traffic(args, None, SCORING_TRAFFIC_PROFILE),
+            'bytes/launch (profiles/r03_scoring_hbm_traffic.json)', args.score_steps)
+        if sroof is not None:
+            scoring['roofline'] = sroof
             a = score_kernels.get('gat_aggregate_fwd')
             if a and a[2] > 0:
                 entry = message_passing_entry(
@@ -426,27 +475,9 @@ def main():
         return
     if rank == 0:
         value = B * world * args.steps / elapsed
-        g = kernel_summary.get('gemm_f32', (0, 0.0, 0.0))
-        roof = None
-        if g[2] > 0:
-            tf = g[1] / (g[2] * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': GEMM_KERNEL, 'achieved': tf,
-                    'peak': GEMM_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'peak_is': 'dense bf16 MFMA peak (2500 TFLOP/s) / 6 partial products; achieved '
-                               'counts algorithmic 2*M*N*K flops',
-                    'frac': tf / GEMM_PEAK_TFLOPS, 'traffic': measured_traffic(args),
-                    'traffic_unit': 'bytes/launch (profiles/r02i_hbm_traffic.json)',
-                    'launches': g[0], 'avg_ms': g[2] / max(g[0], 1),
-                    'share_of_step': g[2] * 1e-3 / elapsed}
-            # the same figure for the shapes that carry the time (the aggregate above also
-            # holds the skinny K=40 / N=50 layers and the [512,10] MLP heads)
-            tags = sorted(train_gemm_tags.items(), key=lambda kv: -kv[1][2])[:4]
-            roof['top_shapes'] = [
-                {'m': t[0], 'n': t[1], 'k': t[2], 'trans_a': t[3], 'trans_b': t[4],
-                 'launches_per_step': c / args.steps, 'ms_per_step': ms / args.steps,
-                 'achieved': w / (ms * 1e-3) / 1e12,
-                 'frac': w / (ms * 1e-3) / 1e12 / GEMM_PEAK_TFLOPS}
-                for t, (c, w, ms) in tags]
+        roof, gemm_ideal_s, gemm_ms = gemm_roofline(
+            train_gemm_tags, elapsed, measured_traffic(args),
+            'bytes/launch (profiles/r03_hbm_traffic.json)', args.steps)
         others = {}
         pmc_names = {'gat_aggregate_fwd': 'gat_aggregate_fwd_kernel',
                      'gat_aggregate_bwd': 'gat_bwd_fused_kernel'}
@@ -459,9 +490,8 @@ def main():
         # ideal time (flops / MFMA peak, or algorithmic bytes / HBM peak) over the measured step;
         # kernels without a work model count as zero ideal time, so this is a lower bound
         ideal_s = attributed_ms = 0.0
-        if 'gemm_f32' in kernel_summary:
-            ideal_s += kernel_summary['gemm_f32'][1] / (GEMM_PEAK_TFLOPS * 1e12)
-            attributed_ms += kernel_summary['gemm_f32'][2]
+        ideal_s += gemm_ideal_s
+        attributed_ms += gemm_ms
         for name, entry in others.items():        # compulsory bytes at the HBM peak
             ideal_s += entry['achieved'] * entry['avg_ms'] * entry['launches'] * 1e-3 / HBM_PEAK_GBS
             attributed_ms += kernel_summary[name][2]
@@ -469,13 +499,13 @@ def main():
         # of the kernel it replaced, is kept beside it so that rounds can be compared)
         ideal_f32 = ideal_s
         if 'gemm_f32' in kernel_summary:
-            ideal_f32 += kernel_summary['gemm_f32'][1] * (1.0 / 157.3e12 - 1.0 / (GEMM_PEAK_TFLOPS * 1e12))
+            ideal_f32 += kernel_summary['gemm_f32'][1] / 157.3e12 - gemm_ideal_s
         step_roof = {'ideal_ms_per_step': 1e3 * ideal_s / args.steps,
                      'measured_ms_per_step': 1e3 * elapsed / args.steps,
                      'frac': ideal_s / elapsed,
                      'frac_with_gemm_at_fp32_matrix_peak': ideal_f32 / elapsed,
                      'attributed_share_of_step': attributed_ms * 1e-3 / elapsed,
-                     'covers': 'gemm_f32 against bf16 MFMA peak / 6, gat_aggregate_fwd/bwd '
+                     'covers': 'gemm_f32 against the 16-bit MFMA peak / 3 (fp16 forms) or / 6 (bf16 form), gat_aggregate_fwd/bwd '
                                '(compulsory bytes) against HBM; every other kernel counts as zero '
                                'ideal time (lower bound). '
                                'The step is compute-dominated: the HBM figures refer to the '

@@ -138,11 +138,17 @@ int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int64_t num_ed
 
 /* ------------------------------------------------------------------------------------
  * dense layers: C[M,N] = row_scale[m] * (op(A)[M,K] . op(B)[K,N]) + bias[n]
- * fp32 in / fp32 out, fp32-accurate: each operand element is split into three bf16 pieces and
- * the six partial products of weight >= 2^-16 are accumulated in fp32 on
- * v_mfma_f32_32x32x16_bf16 (no other precision exists; the error against float64 is below that
- * of an fp32 fma chain, tests/test_gpu_ops.py::test_gemm_error_against_float64...).  An
- * infinite operand element gives NaN where an fp32 chain gives inf.
+ * fp32 in / fp32 out, fp32-accurate on the 16-bit matrix cores, in one of two forms chosen by
+ * shape (tv_gemm_f32_last_form() tells which one the calling thread's last product took):
+ *   form 1, 2 - the layer products and weight gradients of many rows (128 x 256 tiles): each
+ *     operand is scaled by a power of two taken from its largest magnitude (a pass over the
+ *     operand), split into TWO fp16 pieces x0 + 2^-11 x1 (11 + 11 bits), and the three partial
+ *     products a0 b0 | a0 b1 + a1 b0 are accumulated in fp32 on v_mfma_f32_32x32x16_f16;
+ *   form 0 - every other shape: three bf16 pieces per element, six partial products on
+ *     v_mfma_f32_32x32x16_bf16, no scaling.
+ * Either way the error against float64 is below that of an fp32 fma chain
+ * (tests/test_gpu_ops.py::test_gemm_error_against_float64...).  An infinite operand element
+ * gives NaN where an fp32 chain gives inf.
  * row-major storage; transX = 0: stored as written, 1: stored transposed.  lda, ldb < 2^22.
  *
  * Replaces nn.Linear inside dgl.nn.GATConv.fc (model/gnn_layers.py:134-143), the matmul
@@ -161,6 +167,7 @@ int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int64_t num_ed
  * the rounded k must be readable; their values do not matter).
  * ---------------------------------------------------------------------------------- */
 int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int tv_gemm_f32_last_form(void);
 int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
                 int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc,
                 const float *bias, const float *row_scale, int accumulate, void *workspace,

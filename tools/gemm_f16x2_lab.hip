@@ -1,0 +1,245 @@
+// LAB (not part of the library): the fp32 product from TWO fp16 planes per operand and THREE
+// matrix instructions per algorithmic product, against the three bf16 planes / six instructions of
+// csrc/gemm_f32.hip.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o tools/gemm_f16x2_lab tools/gemm_f16x2_lab.hip
+//   tools/gemm_f16x2_lab [M N K reps]
+//
+// x * s = x0 + 2^-11 x1 with x0 = fp16(x s), x1 = fp16((x s - x0) 2^11): 11 + 11 significant bits,
+// s a power of two per TENSOR that puts max|x| into [2^14, 2^15) (fp16 overflows at 2^16; elements
+// down to 2^-29 of the maximum keep all 22 bits, smaller ones lose one bit per binade).  The
+// residual is kept at the scale of x0 (Ootomo & Yokota's form), so it never underflows before x0
+// does.  C = [a0 b0] + 2^-11 [a0 b1 + a1 b0], the two brackets in separate fp32 accumulators;
+// the dropped a1 b1 is below 2^-22 |a b|.  fp16 x fp16 products are exact in fp32.
+// Structure: the eight-wave 128x256 form of tools/gemm_planes_lab.hip (both operands as ready-made
+// plane images by LDS-DMA, one raw barrier per k-tile), with 16 KB images instead of 24 KB.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int PLANE_BYTES = BM * 64;
+constexpr int OPERAND_BYTES = 2 * PLANE_BYTES;     // 16 KB
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned plane_offset(int row, int piece) {
+  return (unsigned)(row * 64 + ((((piece >> 1) ^ (row >> 2)) & 3) << 4) + ((piece & 1) << 3));
+}
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  const f32x2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ f32x2v unpack_f16(unsigned p) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2v);
+}
+
+// X [rows][K] fp32 -> images [row tile][k tile][2 planes], zero outside
+__global__ __launch_bounds__(256) void split_kernel(const float *X, int64_t ld, int64_t R, int64_t K,
+                                                    int64_t ktiles, float scale, char *planes) {
+  const int t = threadIdx.x;
+  const int64_t tr = blockIdx.x / ktiles, kt = blockIdx.x % ktiles;
+  char *image = planes + (int64_t)blockIdx.x * OPERAND_BYTES;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = (t >> 3) + 32 * a, piece = t & 7;
+    const int64_t n = tr * BM + row, k0 = kt * BK + 4 * piece;
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = (n < R && k0 + j < K) ? X[n * ld + k0 + j] * scale : 0.f;
+    const unsigned p01 = pack_f16(x[0], x[1]), p23 = pack_f16(x[2], x[3]);
+    const f32x2v h01 = unpack_f16(p01), h23 = unpack_f16(p23);
+    const unsigned q01 = pack_f16((x[0] - h01[0]) * 2048.f, (x[1] - h01[1]) * 2048.f);
+    const unsigned q23 = pack_f16((x[2] - h23[0]) * 2048.f, (x[3] - h23[1]) * 2048.f);
+    char *dst = image + plane_offset(row, piece);
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(p01, p23);
+    *reinterpret_cast<uint2 *>(dst + PLANE_BYTES) = make_uint2(q01, q23);
+  }
+}
+
+__device__ __forceinline__ void read_set(const char *lds, int row0, int lane, int step, f16x8 (&f)[2]) {
+  const int rowi = row0 + (lane & 31);
+  const char *p = lds + plane_offset(rowi, 2 * (2 * step + (lane >> 5)));
+  f[0] = *reinterpret_cast<const f16x8 *>(p);
+  f[1] = *reinterpret_cast<const f16x8 *>(p + PLANE_BYTES);
+}
+__device__ __forceinline__ void mma3(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x16 &hi, f32x16 &lo) {
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], hi, 0, 0, 0);
+}
+
+// one k-tile global -> LDS: A image and two B images, 16 chunks of 1 KB each, 8 waves: 2 per image
+__device__ __forceinline__ void stage(const char *a_img, const char *b_img, int64_t b_stride, char *buf,
+                                      int wave, int lane) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  const unsigned voff = (unsigned)(wave * 2 * 1024 + lane * 16), loff = (unsigned)(wave * 2 * 1024);
+#pragma unroll
+  for (int img = 0; img < 3; ++img) {
+    const char *src = img == 0 ? a_img : b_img + (int64_t)(img - 1) * b_stride;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      __builtin_amdgcn_global_load_lds((const void *)(src + voff + c * 1024),
+                                       (lds_void *)(buf + img * OPERAND_BYTES + loff + c * 1024), 16, 0, 0);
+  }
+}
+
+template <int PERSIST, int NBUFS>
+__global__ __launch_bounds__(512) void gemm_f16x2_kernel(const char *A, const char *B, float *C, int64_t M,
+                                                         int64_t N, int64_t ldc, int tiles_m, int tiles_n,
+                                                         int ktiles, float inv_scale) {
+  extern __shared__ __align__(16) char smem[];        // NBUFS x (A image | 2 B images)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int BUF_BYTES = 3 * OPERAND_BYTES;
+  const int wm = wave >> 2, wn = wave & 3;
+  tiles_n /= 2;
+  const int ntiles = tiles_m * tiles_n;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int per = ntiles >> 3;
+    const int L = (tile & 7) * per + (tile >> 3);
+    const int tn = L % tiles_n, tm = L / tiles_n;
+    const char *a_img = A + (int64_t)tm * ktiles * OPERAND_BYTES;
+    const char *b_img = B + (int64_t)tn * 2 * ktiles * OPERAND_BYTES;
+    f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+    __builtin_amdgcn_s_barrier();
+    constexpr int PER_WAVE = 6, AHEAD = NBUFS - 1;
+    const int64_t bs = (int64_t)ktiles * OPERAND_BYTES;
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p)
+      if (p < ktiles)
+        stage(a_img + (int64_t)p * OPERAND_BYTES, b_img + (int64_t)p * OPERAND_BYTES, bs, smem + p * BUF_BYTES, wave, lane);
+    for (int it = 0; it < ktiles; ++it) {
+      // tile `it` has landed; up to AHEAD - 1 younger tiles stay in flight
+      if (AHEAD >= 2 && it + 1 < ktiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_WAVE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (it + AHEAD < ktiles)
+        stage(a_img + (int64_t)(it + AHEAD) * OPERAND_BYTES, b_img + (int64_t)(it + AHEAD) * OPERAND_BYTES,
+              bs, smem + ((it + AHEAD) % NBUFS) * BUF_BYTES, wave, lane);
+      const char *As = smem + (it % NBUFS) * BUF_BYTES, *Bs = As + OPERAND_BYTES + (wn >> 1) * OPERAND_BYTES;
+      f16x8 P[2], Q[2], R[2], S[2];
+      read_set(As, wm * 64, lane, 0, P);
+      read_set(Bs, (wn & 1) * 64, lane, 0, Q);
+      read_set(Bs, (wn & 1) * 64 + 32, lane, 0, R);
+      read_set(As, wm * 64 + 32, lane, 0, S);
+      __builtin_amdgcn_sched_barrier(0);
+      mma3(P, Q, hi[0][0], lo[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma3(P, R, hi[0][1], lo[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(As, wm * 64, lane, 1, P);
+      mma3(S, R, hi[1][1], lo[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(Bs, (wn & 1) * 64 + 32, lane, 1, R);
+      mma3(S, Q, hi[1][0], lo[1][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_set(Bs, (wn & 1) * 64, lane, 1, Q);
+      read_set(As, wm * 64 + 32, lane, 1, S);
+      mma3(P, R, hi[0][1], lo[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma3(P, Q, hi[0][0], lo[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma3(S, Q, hi[1][0], lo[1][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma3(S, R, hi[1][1], lo[1][1]);
+    }
+    const int kh = lane >> 5, xl = lane & 31;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 32 + xl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * 64 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+          if (row < M && col < N) C[row * ldc + col] = (hi[i][j][r] + lo[i][j][r] * (1.f / 2048.f)) * inv_scale;
+        }
+      }
+    if (!PERSIST) break;
+  }
+}
+
+int main(int argc, char **argv) {
+  const int64_t M = argc > 1 ? atoll(argv[1]) : 51200, N = argc > 2 ? atoll(argv[2]) : 1024;
+  const int64_t K = argc > 3 ? atoll(argv[3]) : 1024;
+  const int reps = argc > 4 ? atoi(argv[4]) : 50;
+  const int zero = argc > 5 ? atoi(argv[5]) : 0;
+  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN), ktiles = (int)((K + BK - 1) / BK);
+  if ((tiles_m * tiles_n) % 16 || tiles_n % 2) { fprintf(stderr, "tile count must be a multiple of 16 and the column tiles even\n"); return 1; }
+  std::vector<float> ha((size_t)M * K), hb((size_t)N * K);
+  srand(1);
+  // A: values over many octaves (a row factor 2^-10 .. 2^10), B: N(0, 0.03)-like weights
+  for (int64_t r = 0; r < M; ++r) {
+    const float rowf = zero ? 0.f : ldexpf(1.f, (int)(r % 21) - 10);
+    for (int64_t k = 0; k < K; ++k) ha[r * K + k] = ((float)rand() / RAND_MAX * 2.f - 1.f) * rowf;
+  }
+  for (auto &v : hb) v = zero ? 0.f : ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.03f;
+  float amax_a = 0, amax_b = 0;
+  for (auto v : ha) amax_a = fmaxf(amax_a, fabsf(v));
+  for (auto v : hb) amax_b = fmaxf(amax_b, fabsf(v));
+  auto pow2_scale = [](float amax) { int e; frexpf(amax > 0 ? amax : 1.f, &e); return ldexpf(1.f, 15 - e); };   // max -> [2^14, 2^15)
+  const float sa = pow2_scale(amax_a), sb = pow2_scale(amax_b);
+  float *dA, *dB, *dC;
+  char *pA, *pB;
+  CHECK(hipMalloc(&dA, ha.size() * 4)); CHECK(hipMalloc(&dB, hb.size() * 4)); CHECK(hipMalloc(&dC, (size_t)M * N * 4));
+  CHECK(hipMalloc(&pA, (size_t)tiles_m * ktiles * OPERAND_BYTES)); CHECK(hipMalloc(&pB, (size_t)tiles_n * ktiles * OPERAND_BYTES));
+  CHECK(hipMemcpy(dA, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dB, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(split_kernel, dim3(tiles_m * ktiles), dim3(256), 0, 0, dA, K, M, K, (int64_t)ktiles, sa, pA);
+  hipLaunchKernelGGL(split_kernel, dim3(tiles_n * ktiles), dim3(256), 0, 0, dB, K, N, K, (int64_t)ktiles, sb, pB);
+  CHECK(hipDeviceSynchronize());
+  const float inv = (1.f / sa) * (1.f / sb);
+  auto run = [&](auto kern, const char *name, int nbufs, int persist) {
+    const size_t lds = (size_t)nbufs * 3 * OPERAND_BYTES;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = persist ? 256 : tiles_m * tiles_n / 2;
+    for (int i = 0; i < 3; ++i)
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, pA, pB, dC, M, N, N, tiles_m, tiles_n, ktiles, inv);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i)
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, pA, pB, dC, M, N, N, tiles_m, tiles_n, ktiles, inv);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    printf("%-52s %lld x %lld x %lld  %.3f ms  %.1f TF (algorithmic)\n", name, (long long)M, (long long)N,
+           (long long)K, ms, 2.0 * M * N * K / ms / 1e9);
+  };
+  run(gemm_f16x2_kernel<0, 2>, "f16x2 128x256, 8 waves, 2 buffers", 2, 0);
+  run(gemm_f16x2_kernel<1, 2>, "f16x2 128x256, 8 waves, 2 buffers, persistent", 2, 1);
+  run(gemm_f16x2_kernel<0, 3>, "f16x2 128x256, 8 waves, 3 buffers", 3, 0);
+  run(gemm_f16x2_kernel<1, 3>, "f16x2 128x256, 8 waves, 3 buffers, persistent", 3, 1);
+  std::vector<float> hc((size_t)M * N);
+  CHECK(hipMemcpy(hc.data(), dC, hc.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0, worst32 = 0;
+  for (int s = 0; s < 4000; ++s) {
+    const int64_t r = (int64_t)rand() % M, c = (int64_t)rand() % N;
+    double ref = 0, scale = 0;
+    float f32 = 0.f;
+    for (int64_t k = 0; k < K; ++k) {
+      ref += (double)ha[r * K + k] * hb[c * K + k];
+      scale += fabs((double)ha[r * K + k] * hb[c * K + k]);
+      f32 = fmaf(ha[r * K + k], hb[c * K + k], f32);
+    }
+    if (scale == 0) continue;
+    worst = fmax(worst, fabs(hc[r * N + c] - ref) / scale);
+    worst32 = fmax(worst32, fabs((double)f32 - ref) / scale);
+  }
+  printf("max |err| / sum|a||b| over 4000 sampled entries: f16x2 %.2e, fp32 fma chain %.2e\n", worst, worst32);
+  return worst < 1e-6 ? 0 : 2;
+}

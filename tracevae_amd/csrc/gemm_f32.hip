@@ -81,6 +81,8 @@ struct GemmArgs {
   // B already split (gemm_split_b_kernel): LDS images of its tiles, [n-tile][k-tile][24 KB]
   const char *b_planes;
   int64_t b_ktiles;
+  // the fp16 forms: 256 partial maxima of |operand| each (gemm_amax_kernel)
+  const float *a_amax, *b_amax;
 };
 
 // Epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -1330,6 +1332,627 @@ __global__ __launch_bounds__(512) void gemm_kmajor_wide_kernel(GemmArgs g) {
             hi[i][j][q] + lo[i][j][q];
 }
 
+// ------------------------------------------------------------------------------------------
+// The two wide forms on TWO fp16 planes per operand and THREE matrix instructions per product.
+//
+//   x s = x0 + 2^-11 x1,   x0 = fp16(x s),   x1 = fp16((x s - x0) 2^11)        (11 + 11 bits)
+//   C   = [a0 b0] + 2^-11 [a0 b1 + a1 b0],   the brackets in separate fp32 accumulators
+//
+// s is a power of two per OPERAND (exact to apply and to take out again) that puts max|x| into
+// [2^14, 2^15): fp16 overflows at 2^16, elements down to 2^-29 of the operand's maximum keep all
+// 22 bits and smaller ones lose one bit per binade - an absolute error below 2^-37 of the maximum.
+// The residual is kept at the scale of x0 (Ootomo & Yokota, "Recovering single precision accuracy
+// from Tensor Cores ..."), so it cannot underflow before x0 does.  fp16 x fp16 products are exact
+// in fp32; the dropped a1 b1 and the rounding of x1 are below 2^-22 |a b| each.  Measured against
+// float64 (tools/gemm_f16x2_lab.hip, 51200 x 1024 x 1024 with row magnitudes over 20 binades):
+// 6.0e-8 of sum|a||b| against 5.3e-8 for the three-plane bf16 form and 1.6e-7 for an fp32 fma
+// chain - and 320 TFLOP/s against 200 on the same box: half the matrix instructions and two
+// thirds of the LDS bytes per k-tile, on a chip whose clock follows the energy of a k-tile.
+// max|x| comes from gemm_amax_kernel (a pass over the operand, behind the same prologue as the
+// product applies; 256 partial maxima that every workgroup of the product reduces itself: no
+// atomics, no host round trip).  Operands that hold inf / NaN give NaN.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int H_OPERAND_BYTES = 2 * PLANE_BYTES;       // 16 KB
+constexpr int H_BUF_BYTES = 3 * H_OPERAND_BYTES;       // A image | two B images
+constexpr int AMAX_SLOTS = 256;
+constexpr float H_LO = 1.0f / 2048.0f;
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  const f32x2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+// two elements -> their packed head and (scaled) residual halves
+__device__ __forceinline__ void split_f16(float a, float b, unsigned &head, unsigned &res) {
+  head = pack_f16(a, b);
+  const f32x2v h = __builtin_convertvector(__builtin_bit_cast(f16x2, head), f32x2v);
+  res = pack_f16((a - h[0]) * 2048.f, (b - h[1]) * 2048.f);
+}
+// power-of-two scale that puts amax into [2^14, 2^15), and its inverse
+__device__ __forceinline__ void pow2_scale(float amax, float &s, float &inv) {
+  const unsigned b = (__float_as_uint(amax) >> 23) & 255u;
+  if (b < 15u || b == 255u) { s = 1.f; inv = 1.f; return; }   // zero / denormal-range / inf, NaN
+  s = __uint_as_float((268u - b) << 23);
+  inv = __uint_as_float((b - 14u) << 23);
+}
+__device__ __forceinline__ float reduce_amax_slots(const float *slots, int lane) {
+  float m = fmaxf(fmaxf(slots[lane], slots[lane + 64]), fmaxf(slots[lane + 128], slots[lane + 192]));
+  m = tv_wave_max(m);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+
+// max |v| over a row-major [rows][cols] operand, v = x or lrelu(x * scale[col] + shift[col]).
+// 256 workgroups of 1024 threads; thread t walks the float4 columns t % 256, t % 256 + 256, ... of
+// rows ((it * 256 + wg) * 4 + t / 256) * 4 + u, u = 0..3 (sixteen rows of loads in flight per
+// workgroup); columns beyond a multiple of four, or an operand that cannot be read 16 bytes at a
+// time, go one float at a time.  A NaN is skipped by fmaxf and reaches the result through the
+// product itself.
+template <bool ACT>
+__global__ __launch_bounds__(1024) void gemm_amax_kernel(const float *__restrict__ X, int64_t ld,
+                                                         int64_t rows, int64_t cols, int vec,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, float slope,
+                                                         float *__restrict__ slots) {
+  __shared__ float s_red[16];
+  const int t = threadIdx.x, sub = t >> 8, tc = t & 255;
+  const int64_t c4n = vec ? cols >> 2 : 0;
+  float m = 0.f;
+  for (int64_t c4 = tc; c4 < c4n; c4 += 256) {
+    f32x4 cs = {1.f, 1.f, 1.f, 1.f}, ch = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (ACT) {
+      cs = *reinterpret_cast<const f32x4 *>(scale + 4 * c4);
+      ch = *reinterpret_cast<const f32x4 *>(shift + 4 * c4);
+    }
+    for (int64_t r0 = (((int64_t)blockIdx.x) * 4 + sub) * 4; r0 < rows; r0 += 256 * 16) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + u < rows ? r0 + u : rows - 1;
+        v[u] = *reinterpret_cast<const f32x4 *>(X + r * ld + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = v[u][j];
+          if constexpr (ACT) { a = a * cs[j] + ch[j]; a = fmaxf(a, a * slope); }
+          m = fmaxf(m, fabsf(a));
+        }
+    }
+  }
+  // what is left: columns 4 c4n .. cols - 1
+  const int64_t cfirst = 4 * c4n;
+  for (int64_t c = cfirst + tc; c < cols; c += 256) {
+    const float cs = ACT ? scale[c] : 1.f, ch = ACT ? shift[c] : 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + sub; r < rows; r += 256 * 4) {
+      float a = X[r * ld + c];
+      if constexpr (ACT) { a = a * cs + ch; a = fmaxf(a, a * slope); }
+      m = fmaxf(m, fabsf(a));
+    }
+  }
+  m = tv_wave_max(m);
+  if ((t & 63) == 0) s_red[t >> 6] = m;
+  __syncthreads();
+  if (t == 0) {
+    float w = s_red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) w = fmaxf(w, s_red[i]);
+    slots[blockIdx.x] = w;
+  }
+}
+
+// B split once per call into the fp16 LDS images of its tiles (16 KB each), scaled by the power
+// of two that `slots` (its gemm_amax_kernel result) gives.  Layout of a plane as in the bf16 form.
+__global__ __launch_bounds__(256) void gemm_split_b_h_kernel(const float *B, int64_t ldb, int kx,
+                                                             int64_t N, int64_t K, int64_t ktiles,
+                                                             const float *slots, char *planes) {
+  const int t = threadIdx.x;
+  float sb, inv;
+  pow2_scale(reduce_amax_slots(slots, t & 63), sb, inv);
+  const int64_t tn = blockIdx.x / ktiles, kt = blockIdx.x % ktiles;
+  char *image = planes + (int64_t)blockIdx.x * H_OPERAND_BYTES;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = kx ? (t & 31) + 32 * a : (t >> 3) + 32 * a;
+    const int piece = kx ? (t >> 5) : (t & 7);
+    const int64_t n = tn * BN + row, k0 = kt * BK + 4 * piece;
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t k = k0 + j;
+      x[j] = (n < N && k < K) ? (kx ? B[k * ldb + n] : B[n * ldb + k]) * sb : 0.f;
+    }
+    unsigned p01, p23, q01, q23;
+    split_f16(x[0], x[1], p01, q01);
+    split_f16(x[2], x[3], p23, q23);
+    char *dst = image + plane_offset(row, piece);
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(p01, p23);
+    *reinterpret_cast<uint2 *>(dst + PLANE_BYTES) = make_uint2(q01, q23);
+  }
+}
+
+__device__ __forceinline__ void read_set_h(const char *lds, int row0, int lane, int step, f16x8 (&f)[2]) {
+  const int rowi = row0 + (lane & 31);
+  const char *p = lds + plane_offset(rowi, 2 * (2 * step + (lane >> 5)));
+  f[0] = *reinterpret_cast<const f16x8 *>(p);
+  f[1] = *reinterpret_cast<const f16x8 *>(p + PLANE_BYTES);
+}
+// the three partial products of one 32x32 tile for one k-step: a0 b0 -> hi, the corrections -> lo
+__device__ __forceinline__ void mma3(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x16 &hi, f32x16 &lo) {
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], hi, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wide_stage_b_h(const char *b_img, int64_t b_stride, char *buf, int wave, int lane) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  // 32 chunks of 1 KB over 8 waves: 2 per image and wave, lane-linear (the images are byte copies)
+  const unsigned voff = (unsigned)(wave * 2 * 1024 + lane * 16), loff = (unsigned)(wave * 2 * 1024);
+#pragma unroll
+  for (int img = 0; img < 2; ++img)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      __builtin_amdgcn_global_load_lds((const void *)(b_img + (int64_t)img * b_stride + voff + c * 1024),
+                                       (lds_void *)(buf + img * H_OPERAND_BYTES + loff + c * 1024), 16, 0, 0);
+}
+
+// two fp16 planes of 8 consecutive k of one row into the A image (stores the compiler does not see)
+__device__ __forceinline__ void wide_split_store_h(const f32x4 &u, const f32x4 &v, char *dst) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w0, w1;
+  unsigned a, b;
+  split_f16(u[0], u[1], a, b); w0[0] = a; w1[0] = b;
+  split_f16(u[2], u[3], a, b); w0[1] = a; w1[1] = b;
+  split_f16(v[0], v[1], a, b); w0[2] = a; w1[2] = b;
+  split_f16(v[2], v[3], a, b); w0[3] = a; w1[3] = b;
+  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dst;
+  static_assert(PLANE_BYTES == 8192, "plane offset below");
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w0) : "memory");
+  asm volatile("ds_write_b128 %0, %1 offset:8192" ::"v"(addr), "v"(w1) : "memory");
+}
+
+// gemm_wide_kernel on fp16 planes: same tile (128 x 256), same eight multiplying waves, same
+// pipeline (B's images by LDS-DMA, A split by the multiplying waves between their matrix
+// instructions, two LDS buffers, one raw barrier per k-tile, loads and DMAs counted by hand);
+// per wave and k-tile 24 matrix instructions and 16 ds_read_b128 (48 and 24 there), 4 DMAs (6).
+// The buffers are 48 KB, so the output staging area (64 KB) lies behind them instead of inside
+// the buffer the last k-tile left free.
+template <bool ACT>
+__global__ __launch_bounds__(512) void gemm_wide_h_kernel(GemmArgs g) {
+  extern __shared__ __align__(16) char smem[];        // 2 x (A image | 2 B images) | staging
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  constexpr int LA = ACT ? 6 : 2;                      // loads per thread and k-tile: A (+ coefficients)
+  constexpr int NDMA = 4;                              // LDS-DMA instructions per wave and k-tile
+
+  float sa, inv_a, sb, inv_b;
+  pow2_scale(reduce_amax_slots(g.a_amax, lane), sa, inv_a);
+  pow2_scale(reduce_amax_slots(g.b_amax, lane), sb, inv_b);
+
+  const int tail_units = g.tail_splits > 1;
+  const int nwg = tail_units ? (int)g.tail_first : (int)g.units;
+  const int u_id = blockIdx.x;
+  const bool tail = tail_units && u_id >= nwg;
+  int tile, sp = 0;
+  int64_t kchunk = g.K;
+  if (tail) {
+    const int v = u_id - nwg;
+    tile = nwg + v / (int)g.tail_splits;
+    sp = v % (int)g.tail_splits;
+    kchunk = g.tail_kchunk;
+  } else {
+    const int q = nwg >> 3, rr = nwg & 7;
+    const int xcd = u_id & 7, idx = u_id >> 3;
+    tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  tile = __builtin_amdgcn_readfirstlane(tile);
+  sp = __builtin_amdgcn_readfirstlane(sp);
+  const int tn = tile % (int)g.tiles_n, tm = tile / (int)g.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * WBN;
+  const int64_t kbeg = sp * kchunk;
+  const int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
+  const int64_t klen = kend - kbeg;
+  const int ntf = __builtin_amdgcn_readfirstlane((int)(klen / BK));
+  const int rem = __builtin_amdgcn_readfirstlane((int)(klen - (int64_t)ntf * BK));
+  const int nt = ntf + (rem ? 1 : 0);
+  const int nfull = (rem > 0 && rem <= 16) ? nt - 1 : nt;
+
+  int64_t arow = t >> 2;
+  if (m0 + arow >= g.M) arow = g.M - 1 - m0;
+  const int kq = 8 * (t & 3);
+  const unsigned a_off = (unsigned)((arow * g.lda + kq) * 4);
+  const unsigned a_lds = plane_offset(t >> 2, 2 * (t & 3));
+  const char *a_base = reinterpret_cast<const char *>(g.A + m0 * g.lda + kbeg);
+  const char *cs_base = reinterpret_cast<const char *>(g.act_scale + kbeg);
+  const char *ch_base = reinterpret_cast<const char *>(g.act_shift + kbeg);
+  const char *b_img = g.b_planes + ((int64_t)tn * 2 * g.b_ktiles + kbeg / BK) * H_OPERAND_BYTES;
+  const int64_t bs = g.b_ktiles * (int64_t)H_OPERAND_BYTES;
+
+  f32x4 u, v, su, sv, hu, hv;
+  auto load_a = [&](int kt) {
+    const char *tp = a_base + (int64_t)kt * (BK * 4);
+    unsigned ou = a_off, ov = a_off + 16, cu = 4u * kq, cv = 4u * kq + 16;
+    if (kt >= ntf) {
+      if (kq >= rem) { ou = a_off - 4u * kq; cu = 0; }
+      if (kq + 4 >= rem) { ov = a_off - 4u * kq; cv = 0; }
+    }
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(u) : "v"(ou), "s"(tp));
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(ov), "s"(tp));
+    if constexpr (ACT) {
+      const char *sp_ = cs_base + (int64_t)kt * (BK * 4), *hp_ = ch_base + (int64_t)kt * (BK * 4);
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(su) : "v"(cu), "s"(sp_));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sv) : "v"(cv), "s"(sp_));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hu) : "v"(cu), "s"(hp_));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hv) : "v"(cv), "s"(hp_));
+    }
+  };
+  auto split_a = [&](int kt) {
+    if constexpr (ACT) asm volatile("" : "+v"(u), "+v"(v), "+v"(su), "+v"(sv), "+v"(hu), "+v"(hv));
+    else asm volatile("" : "+v"(u), "+v"(v));
+    if constexpr (ACT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = u[j] * su[j] + hu[j], b = v[j] * sv[j] + hv[j];
+        u[j] = fmaxf(a, a * g.act_slope);
+        v[j] = fmaxf(b, b * g.act_slope);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u[j] *= sa; v[j] *= sa; }
+    if (kt >= ntf) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (kq + j >= rem) u[j] = 0.f;
+        if (kq + 4 + j >= rem) v[j] = 0.f;
+      }
+    }
+    wide_split_store_h(u, v, smem + (kt & 1) * H_BUF_BYTES + a_lds);
+  };
+
+  f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+
+  wide_stage_b_h(b_img, bs, smem + H_OPERAND_BYTES, wave, lane);
+  load_a(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  split_a(0);
+  if (nt > 1) load_a(1);
+
+  for (int it = 0; it < nfull; ++it) {
+    const bool more = it + 1 < nt;
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (more)
+      wide_stage_b_h(b_img + (int64_t)(it + 1) * H_OPERAND_BYTES, bs,
+                     smem + ((it + 1) & 1) * H_BUF_BYTES + H_OPERAND_BYTES, wave, lane);
+    const char *As = smem + (it & 1) * H_BUF_BYTES;
+    const char *Bs = As + H_OPERAND_BYTES + (wn >> 1) * H_OPERAND_BYTES;
+    const int bn0 = (wn & 1) * 64;
+    f16x8 P[2], Q[2], R[2], S[2];
+    read_set_h(As, wm * 64, lane, 0, P);
+    read_set_h(Bs, bn0, lane, 0, Q);
+    read_set_h(Bs, bn0 + 32, lane, 0, R);
+    read_set_h(As, wm * 64 + 32, lane, 0, S);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mma3(P, Q, hi[0][0], lo[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(P, R, hi[0][1], lo[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_h(As, wm * 64, lane, 1, P);
+    mma3(S, R, hi[1][1], lo[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_h(Bs, bn0 + 32, lane, 1, R);
+    mma3(S, Q, hi[1][0], lo[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_h(Bs, bn0, lane, 1, Q);
+    read_set_h(As, wm * 64 + 32, lane, 1, S);
+    __builtin_amdgcn_s_setprio(0);
+    if (more) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      split_a(it + 1);
+      if (it + 2 < nt) load_a(it + 2);
+    }
+    mma3(P, R, hi[0][1], lo[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(P, Q, hi[0][0], lo[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(S, Q, hi[1][0], lo[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(S, R, hi[1][1], lo[1][1]);
+  }
+  if (nfull < nt) {                                    // the short last tile: first k-step only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char *As = smem + (nfull & 1) * H_BUF_BYTES;
+    const char *Bs = As + H_OPERAND_BYTES + (wn >> 1) * H_OPERAND_BYTES;
+    const int bn0 = (wn & 1) * 64;
+    f16x8 P[2], Q[2], R[2], S[2];
+    read_set_h(As, wm * 64, lane, 0, P);
+    read_set_h(Bs, bn0, lane, 0, Q);
+    read_set_h(Bs, bn0 + 32, lane, 0, R);
+    read_set_h(As, wm * 64 + 32, lane, 0, S);
+    mma3(P, Q, hi[0][0], lo[0][0]);
+    mma3(P, R, hi[0][1], lo[0][1]);
+    mma3(S, R, hi[1][1], lo[1][1]);
+    mma3(S, Q, hi[1][0], lo[1][0]);
+  }
+
+  // C = (hi + 2^-11 lo) / (sa sb), the two inverse scales applied one after the other (their
+  // product may leave the fp32 range where the result does not)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hi[i][j][r] = ((hi[i][j][r] + lo[i][j][r] * H_LO) * inv_a) * inv_b;
+
+  const int kh = lane >> 5, xl = lane & 31;
+  if (tail) {
+    float *slab = g.tail_slabs + ((int64_t)(tile - nwg) * g.tail_splits + sp) * (BM * WBN);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[(wm * 64 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * WBN + wn * 64 + j * 32 + xl] = hi[i][j][r];
+    return;
+  }
+  const int64_t col0 = n0 + wn * 64 + xl;
+  float bv0 = (g.bias && col0 < g.N) ? g.bias[col0] : 0.f;
+  float bv1 = (g.bias && col0 + 32 < g.N) ? g.bias[col0 + 32] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1)::"memory");
+  if (g.c_vec && m0 + BM <= g.M) {
+    // the wave transposes its block, 32 rows at a time, through its own 8 KB of the staging area
+    // behind the plane buffers and stores 256-byte row segments, non-temporal
+    float *ws = reinterpret_cast<float *>(smem + 2 * H_BUF_BYTES) + wave * (32 * 64);
+    const int c = (lane & 15) * 4;
+    const int64_t col = n0 + wn * 64 + c;
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && col < g.N) bq = *reinterpret_cast<const f32x4 *>(g.bias + col);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq)::"memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ws[(4 * kh + (r & 3) + 8 * (r >> 2)) * 64 + ((j * 32 + xl) ^ (kh << 5))] = hi[i][j][r];
+      if (col < g.N) {
+        float *orow = g.C + (m0 + wm * 64 + i * 32 + (lane >> 4)) * g.ldc + col;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 x = *reinterpret_cast<const f32x4 *>(&ws[(q * 4 + (lane >> 4)) * 64 + (c ^ ((q & 1) << 5))]);
+          __builtin_nontemporal_store(x + bq, reinterpret_cast<f32x4 *>(orow + (int64_t)q * 4 * g.ldc));
+        }
+      }
+    }
+    return;
+  }
+  float *o = g.C + (m0 + wm * 64 + 4 * kh) * g.ldc + col0;
+  const int64_t rbase = m0 + wm * 64 + 4 * kh;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bool colok = col0 + j * 32 < g.N;
+    const float bv = j ? bv1 : bv0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (colok && rbase + rr < g.M) o[rr * g.ldc + j * 32] = hi[i][j][r] + bv;
+      }
+  }
+}
+
+// four x of one k -> 8 bytes in each of the two fp16 planes of a k-major image
+__device__ __forceinline__ void kmajor_split_store_h(const f32x4 &x, char *dst) {
+  unsigned p01, p23, q01, q23;
+  split_f16(x[0], x[1], p01, q01);
+  split_f16(x[2], x[3], p23, q23);
+  *reinterpret_cast<uint2 *>(dst) = make_uint2(p01, p23);
+  *reinterpret_cast<uint2 *>(dst + PLANE_BYTES) = make_uint2(q01, q23);
+}
+
+__device__ __forceinline__ void read_set_tr_h(const char *img, int xbase, int lane, int step, f16x8 (&f)[2]) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int gq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int ch = ((xbase + 16 * (gq & 1)) >> 3) + (p >> 1);
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    s16x4 h[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int row = 16 * step + 8 * (gq >> 1) + 4 * hh + q;
+      const char *a = img + pl * PLANE_BYTES + kmajor_offset(row, ch) + 8 * (p & 1);
+      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)a);
+    }
+    const s16x8 v = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+    f[pl] = __builtin_bit_cast(f16x8, v);
+  }
+}
+
+// gemm_kmajor_wide_kernel on fp16 planes (the weight gradients): same units, same loads, same
+// pipeline; both operands are scaled by their own power of two as they are split.
+template <bool ACT>
+__global__ __launch_bounds__(512) void gemm_kmajor_wide_h_kernel(GemmArgs g) {
+  extern __shared__ __align__(16) char smem[];        // 2 x (A image | 2 B images), k-major
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  float sa, inv_a, sb, inv_b;
+  pow2_scale(reduce_amax_slots(g.a_amax, lane), sa, inv_a);
+  pow2_scale(reduce_amax_slots(g.b_amax, lane), sb, inv_b);
+  const int nsp = (int)g.tail_splits;
+  const int sp = __builtin_amdgcn_readfirstlane((int)blockIdx.x % nsp);
+  const int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x / nsp);
+  const int tn = tile % (int)g.tiles_n, tm = tile / (int)g.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * WBN;
+  const int64_t kbeg = sp * g.tail_kchunk;
+  const int64_t kend = (kbeg + g.tail_kchunk < g.K) ? (kbeg + g.tail_kchunk) : g.K;
+  const int ntf = __builtin_amdgcn_readfirstlane((int)((kend - kbeg) / BK));
+  const int rem = __builtin_amdgcn_readfirstlane((int)(kend - kbeg - (int64_t)ntf * BK));
+
+  const int ax = 4 * (t & 31), ak = t >> 5;
+  const int bx = 4 * (t & 63), bk = t >> 6;
+  const int axc = (m0 + ax < g.M) ? ax : 0, bxc = (n0 + bx < g.N) ? bx : 0;
+  const char *a_base = reinterpret_cast<const char *>(g.A + kbeg * g.lda + m0);
+  const char *b_base = reinterpret_cast<const char *>(g.B + kbeg * g.ldb + n0);
+  auto krow = [&](int j) { return j < 2 ? ak + 16 * j : bk + 8 * (j - 2); };
+  unsigned off[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    off[j] = j < 2 ? (unsigned)((krow(j) * g.lda + axc) * 4) : (unsigned)((krow(j) * g.ldb + bxc) * 4);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (ACT) {
+    sc = *reinterpret_cast<const f32x4 *>(g.act_scale + n0 + bxc);
+    sh = *reinterpret_cast<const f32x4 *>(g.act_shift + n0 + bxc);
+  }
+  f32x4 r[6];
+  auto tile_a = [&](int kt) { return a_base + (int64_t)kt * BK * g.lda * 4; };
+  auto tile_b = [&](int kt) { return b_base + (int64_t)kt * BK * g.ldb * 4; };
+  auto split_piece = [&](int j, char *buf) {
+    if (j < 2) {
+      const f32x4 v = r[j] * sa;
+      kmajor_split_store_h(v, buf + kmajor_offset(krow(j), ax >> 3) + 2 * (ax & 7));
+    } else {
+      f32x4 v = r[j];
+      if constexpr (ACT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = v[e] * sc[e] + sh[e];
+          v[e] = fmaxf(a, a * g.act_slope);
+        }
+      }
+      v *= sb;
+      kmajor_split_store_h(v, buf + H_OPERAND_BYTES + (bx >> 7) * H_OPERAND_BYTES +
+                                  kmajor_offset(krow(j), (bx & 127) >> 3) + 2 * (bx & 7));
+    }
+  };
+
+  f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { hi[i][j][q] = 0.f; lo[i][j][q] = 0.f; }
+
+  // one k-tile out of buffer `As`; piece(j) runs after the j-th block of matrix instructions
+  auto multiply = [&](const char *As, auto &&piece) {
+    const char *Bs = As + H_OPERAND_BYTES + (wn >> 1) * H_OPERAND_BYTES;
+    const int bn0 = (wn & 1) * 64;
+    f16x8 P[2], Q[2], R[2], S[2];
+    read_set_tr_h(As, wm * 64, lane, 0, P);
+    read_set_tr_h(Bs, bn0, lane, 0, Q);
+    read_set_tr_h(Bs, bn0 + 32, lane, 0, R);
+    read_set_tr_h(As, wm * 64 + 32, lane, 0, S);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mma3(P, Q, hi[0][0], lo[0][0]);
+    piece(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(P, R, hi[0][1], lo[0][1]);
+    piece(1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_tr_h(As, wm * 64, lane, 1, P);
+    mma3(S, R, hi[1][1], lo[1][1]);
+    piece(2);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_tr_h(Bs, bn0 + 32, lane, 1, R);
+    mma3(S, Q, hi[1][0], lo[1][0]);
+    piece(3);
+    __builtin_amdgcn_sched_barrier(0);
+    read_set_tr_h(Bs, bn0, lane, 1, Q);
+    read_set_tr_h(As, wm * 64 + 32, lane, 1, S);
+    __builtin_amdgcn_s_setprio(0);
+    mma3(P, R, hi[0][1], lo[0][1]);
+    piece(4);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(P, Q, hi[0][0], lo[0][0]);
+    piece(5);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(S, Q, hi[1][0], lo[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma3(S, R, hi[1][1], lo[1][1]);
+  };
+  auto nothing = [](int) {};
+
+  if (ntf > 0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? tile_a(0) : tile_b(0)));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5])::"memory");
+#pragma unroll
+    for (int j = 0; j < 6; ++j) split_piece(j, smem);
+    const int t1 = ntf > 1 ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? tile_a(t1) : tile_b(t1)));
+    for (int it = 0; it + 1 < ntf; ++it) {
+      __syncthreads();
+      char *other = smem + ((it + 1) & 1) * H_BUF_BYTES;
+      const int kt = it + 2 < ntf ? it + 2 : ntf - 1;
+      const char *ta = tile_a(kt), *tb = tile_b(kt);
+      multiply(smem + (it & 1) * H_BUF_BYTES, [&](int j) {
+        asm volatile("s_waitcnt vmcnt(5)" : "+v"(r[j]));
+        split_piece(j, other);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? ta : tb));
+      });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (rem > 0) {
+    const char *ta = tile_a(ntf), *tb = tile_b(ntf);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int kr = krow(j) < rem ? krow(j) : rem - 1;
+      const unsigned o = j < 2 ? (unsigned)((kr * g.lda + axc) * 4) : (unsigned)((kr * g.ldb + bxc) * 4);
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(o), "s"(j < 2 ? ta : tb));
+    }
+  }
+  if (ntf > 0) {
+    __syncthreads();
+    multiply(smem + ((ntf - 1) & 1) * H_BUF_BYTES, nothing);
+  }
+  if (rem > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5])::"memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (krow(j) >= rem) r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    char *buf = smem + (ntf & 1) * H_BUF_BYTES;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) split_piece(j, buf);
+    __syncthreads();
+    multiply(buf, nothing);
+  }
+
+  const int kh = lane >> 5, xl = lane & 31;
+  float *slab = g.tail_slabs + ((int64_t)tile * nsp + sp) * (BM * WBN);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        slab[(wm * 64 + i * 32 + 4 * kh + (q & 3) + 8 * (q >> 2)) * WBN + wn * 64 + j * 32 + xl] =
+            ((hi[i][j][q] + lo[i][j][q] * H_LO) * inv_a) * inv_b;
+}
+
 // second stage of split-K: out = epilogue(sum_s slab[s]) in slab order
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   const int64_t total = g.M * g.N;
@@ -1407,6 +2030,7 @@ struct Plan {
   // the wide form for k-major operands (gemm_kmajor_wide_kernel): every tile split over K into
   // one round of the chip; 0 splits = not taken
   int64_t km_splits, km_kchunk, km_slab_bytes;
+  int64_t amax_bytes;                               // 2 x 256 partial maxima behind the planes
 };
 
 int64_t choose_splits(int64_t m, int64_t n, int64_t k);
@@ -1480,7 +2104,8 @@ Plan make_plan(int64_t m, int64_t n, int64_t k) {
   }
   if (p.km_slab_bytes > p.slab_bytes) p.slab_bytes = p.km_slab_bytes;
   p.slab_bytes = (p.slab_bytes + 255) & ~255ll;
-  p.workspace_bytes = p.slab_bytes + p.planes_bytes;
+  p.amax_bytes = (p.wide || p.km_splits > 1) ? 2 * AMAX_SLOTS * (int64_t)sizeof(float) : 0;
+  p.workspace_bytes = p.slab_bytes + p.planes_bytes + p.amax_bytes;
   return p;
 }
 
@@ -1508,6 +2133,7 @@ extern "C" int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) 
 }
 
 namespace {
+thread_local int g_last_form = 0;
 int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
              int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, const float *bias,
              const float *row_scale, int accumulate, int act_operand, const float *act_scale,
@@ -1565,14 +2191,23 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   // weight-gradient form, whose B is the activation matrix)
   const bool presplit = plan.planes_bytes > 0 && act_operand != 2;
   g.b_planes = nullptr; g.b_ktiles = tv_cdiv(k, BK);
-  if (presplit) {
-    TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gemm_f32: workspace must be 16-byte aligned");
-    char *planes = (char *)workspace + plan.slab_bytes;
-    g.b_planes = planes;
-    hipLaunchKernelGGL(gemm_split_b_kernel, dim3((unsigned)(((g.tiles_n + 1) & ~1ll) * g.b_ktiles)),
-                       dim3(256), 0, s, b, ldb, trans_b ? 0 : 1, n, k, g.b_ktiles, planes);
-    TV_LAUNCH_CHECK("tv_gemm_f32(split of B)");
+  g.a_amax = g.b_amax = nullptr;
+  float *amax_a = nullptr, *amax_b = nullptr;
+  if (plan.amax_bytes > 0) {
+    amax_a = (float *)((char *)workspace + plan.slab_bytes + plan.planes_bytes);
+    amax_b = amax_a + AMAX_SLOTS;
   }
+  // max |operand| of a row-major [rows][cols] operand (behind its prologue), 256 partial maxima
+  auto launch_amax = [&](const float *x, int64_t ld, int64_t rows, int64_t cols, bool act, float *slots) {
+    const int vec = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
+                    (!act || ((((uintptr_t)act_scale | (uintptr_t)act_shift) & 15) == 0));
+    if (act)
+      hipLaunchKernelGGL(gemm_amax_kernel<true>, dim3(AMAX_SLOTS), dim3(1024), 0, s, x, ld, rows, cols, vec,
+                         act_scale, act_shift, act_slope, slots);
+    else
+      hipLaunchKernelGGL(gemm_amax_kernel<false>, dim3(AMAX_SLOTS), dim3(1024), 0, s, x, ld, rows, cols, vec,
+                         (const float *)nullptr, (const float *)nullptr, 0.f, slots);
+  };
   // the wide form: a row-major A that can be read 16 bytes at a time against the pre-split B,
   // plain epilogue (bias at most)
   // (a K that is not a multiple of 4 is taken too when the rows of A are padded to one: the float4
@@ -1580,7 +2215,26 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   // zero there anyway; not with a prologue, whose coefficient vectors end at K)
   const bool a_rows16 = g.a_vec || (!trans_a && act_operand == 0 && lda % 4 == 0 &&
                                     (((uintptr_t)a & 15) == 0) && lda >= ((k + 3) & ~3ll));
-  if (plan.wide && presplit && !trans_a && a_rows16 && !row_scale && !accumulate && act_operand != 2) {
+  const bool take_wide = plan.wide && presplit && !trans_a && a_rows16 && !row_scale && !accumulate &&
+                         act_operand != 2;
+  if (presplit) {
+    TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gemm_f32: workspace must be 16-byte aligned");
+    char *planes = (char *)workspace + plan.slab_bytes;
+    g.b_planes = planes;
+    const dim3 sgrid((unsigned)(((g.tiles_n + 1) & ~1ll) * g.b_ktiles));
+    if (take_wide) {
+      // B as stored: [n][k] (trans_b) or [k][n]
+      launch_amax(b, ldb, trans_b ? n : k, trans_b ? k : n, false, amax_b);
+      TV_LAUNCH_CHECK("tv_gemm_f32(max of B)");
+      hipLaunchKernelGGL(gemm_split_b_h_kernel, sgrid, dim3(256), 0, s, b, ldb, trans_b ? 0 : 1, n, k,
+                         g.b_ktiles, (const float *)amax_b, planes);
+    } else {
+      hipLaunchKernelGGL(gemm_split_b_kernel, sgrid, dim3(256), 0, s, b, ldb, trans_b ? 0 : 1, n, k,
+                         g.b_ktiles, planes);
+    }
+    TV_LAUNCH_CHECK("tv_gemm_f32(split of B)");
+  }
+  if (take_wide) {
     GemmArgs w = g;
     w.tiles_n = tv_cdiv(n, WBN);
     w.tail_first = plan.w_tail_first; w.tail_splits = plan.w_tail_splits; w.tail_kchunk = plan.w_tail_kchunk;
@@ -1590,26 +2244,31 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
                               : plan.w_tiles;
     TV_REQUIRE(units < (1ll << 31), "tv_gemm_f32: grid too large");
     w.units = units;
-    const size_t wlds = 2 * (size_t)WIDE_BUF_BYTES;
+    w.a_amax = amax_a; w.b_amax = amax_b;
+    launch_amax(a, lda, m, k, act_operand == 1, amax_a);
+    TV_LAUNCH_CHECK("tv_gemm_f32(max of A)");
+    // two plane buffers + the eight waves' output staging behind them
+    const size_t wlds = 2 * (size_t)H_BUF_BYTES + 8 * 32 * 64 * sizeof(float);
     int device = 0;
     TV_HIP(hipGetDevice(&device));
     static bool raised[2][64] = {};
     const int wa = act_operand == 1;
     if (!raised[wa][device & 63]) {
-      if (wa) TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_kernel<true>),
+      if (wa) TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_h_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-      else TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_kernel<false>),
+      else TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_wide_h_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
       raised[wa][device & 63] = true;
     }
-    if (wa) hipLaunchKernelGGL(gemm_wide_kernel<true>, dim3((unsigned)units), dim3(512), wlds, s, w);
-    else hipLaunchKernelGGL(gemm_wide_kernel<false>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    if (wa) hipLaunchKernelGGL(gemm_wide_h_kernel<true>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    else hipLaunchKernelGGL(gemm_wide_h_kernel<false>, dim3((unsigned)units), dim3(512), wlds, s, w);
     TV_LAUNCH_CHECK("tv_gemm_f32(wide)");
     if (w.tail_splits > 1) {
       hipLaunchKernelGGL(gemm_wide_tail_reduce_kernel, dim3((unsigned)((plan.w_tiles - w.tail_first) * 8)),
                          dim3(256), 0, s, w);
       TV_LAUNCH_CHECK("tv_gemm_f32(wide tail reduce)");
     }
+    g_last_form = 1;
     return TV_OK;
   }
   // the wide form for k-major operands (weight gradients): both operands readable 16 bytes at a
@@ -1624,25 +2283,31 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     w.tail_slabs = (float *)workspace;
     const int64_t units = plan.w_tiles * plan.km_splits;
     w.units = units;
-    const size_t wlds = 2 * (size_t)WIDE_BUF_BYTES;
+    w.a_amax = amax_a; w.b_amax = amax_b;
+    launch_amax(a, lda, k, m, false, amax_a);                    // A stored [k][m]
+    launch_amax(b, ldb, k, n, act_operand == 2, amax_b);         // B stored [k][n]
+    TV_LAUNCH_CHECK("tv_gemm_f32(max of the operands)");
+    const size_t wlds = 2 * (size_t)H_BUF_BYTES;
     int device = 0;
     TV_HIP(hipGetDevice(&device));
     static bool raised[2][64] = {};
     const int wa = act_operand == 2;
     if (!raised[wa][device & 63]) {
-      if (wa) TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kmajor_wide_kernel<true>),
+      if (wa) TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kmajor_wide_h_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-      else TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kmajor_wide_kernel<false>),
+      else TV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kmajor_wide_h_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
       raised[wa][device & 63] = true;
     }
-    if (wa) hipLaunchKernelGGL(gemm_kmajor_wide_kernel<true>, dim3((unsigned)units), dim3(512), wlds, s, w);
-    else hipLaunchKernelGGL(gemm_kmajor_wide_kernel<false>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    if (wa) hipLaunchKernelGGL(gemm_kmajor_wide_h_kernel<true>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    else hipLaunchKernelGGL(gemm_kmajor_wide_h_kernel<false>, dim3((unsigned)units), dim3(512), wlds, s, w);
     TV_LAUNCH_CHECK("tv_gemm_f32(k-major wide)");
     hipLaunchKernelGGL(gemm_wide_tail_reduce_kernel, dim3((unsigned)(plan.w_tiles * 8)), dim3(256), 0, s, w);
     TV_LAUNCH_CHECK("tv_gemm_f32(k-major wide reduce)");
+    g_last_form = 2;
     return TV_OK;
   }
+  g_last_form = 0;
   const int64_t tiles = g.tiles_m * g.tiles_n;
   const int64_t nwg = g.tail_splits > 1 ? g.tail_first + (tiles - g.tail_first) * g.tail_splits
                                         : tiles * g.splits;
@@ -1699,6 +2364,8 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   return TV_OK;
 }
 }  // namespace
+
+extern "C" int tv_gemm_f32_last_form(void) { return g_last_form; }
 
 extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k,
                            const float *a, int64_t lda, const float *b, int64_t ldb, float *c,

@@ -43,6 +43,7 @@ class KernelTimer(object):
             self.start = torch.cuda.Event(enable_timing=True)
             self.end = torch.cuda.Event(enable_timing=True)
             self.start.record()
+            return self
 
         def __exit__(self, *exc):
             self.end.record()
@@ -166,7 +167,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
         return c
     wsb = hip.query('tv_gemm_f32_workspace_bytes', m, n, k)
     ws = _workspace(wsb, a.device)
-    with TIMER.region('gemm_f32', 2.0 * m * n * k, (m, n, k, bool(trans_a), bool(trans_b))):
+    with TIMER.region('gemm_f32', 2.0 * m * n * k, (m, n, k, bool(trans_a), bool(trans_b))) as reg:
         if act is None:
             hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a), a.stride(0),
                      hip.ptr_rows(b), b.stride(0), hip.ptr_rows(c), c.stride(0), hip.ptr(bias),
@@ -181,6 +182,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
                      hip.ptr(row_scale), int(accumulate), int(operand),
                      hip.ptr(_check(scale, 'act scale')), hip.ptr(_check(shift, 'act shift')),
                      float(slope), hip.ptr(ws), wsb)
+        if reg is not None:
+            # which arithmetic the product took: 0 = bf16 x 3 (six terms), 1 / 2 = fp16 x 2 (three
+            # terms) on the wide / k-major wide form; the bench prices each against its own peak
+            reg.tag = reg.tag + (int(hip.lib().tv_gemm_f32_last_form()),)
     return c
 
 
