@@ -40,6 +40,8 @@ extern "C" {
 /* limits of tv_realnvp_logprob_* */
 #define TV_FLOW_MAX_LEVELS 8
 #define TV_FLOW_MAX_DIM 20
+/* partial operand maxima kept by the caller of tv_gemm_f32_ex */
+#define TV_GEMM_MAX_SLOTS 256
 
 /* status bits written by tv_batch_build into *status (device int32) */
 #define TV_BATCH_TOO_MANY_NODES 1 /* a trace has more than max_node_count nodes           */
@@ -187,6 +189,24 @@ int tv_gemm_f32_act(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, c
                     const float *bias, const float *row_scale, int accumulate, int act_operand,
                     const float *act_scale, const float *act_shift, float act_slope,
                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/* tv_gemm_f32_act with the operand maxima of the fp16 forms kept by the CALLER, so that a tensor
+ * that enters several products is scanned once (a layer's input x enters its forward product
+ * and its weight gradient; the output gradient enters the input gradient and the weight
+ * gradient; the weights enter forward product and input gradient).  a_max / b_max: 256 floats of
+ * device memory each (TV_GEMM_MAX_SLOTS; partial maxima of |operand| behind its prologue).
+ * state 0: no buffer (the library scans into its workspace); 1: scan the operand into the buffer
+ * if this product needs it; 2: the buffer holds the maxima of exactly this operand view (same
+ * rows, columns and prologue coefficients) - the library does not look at the operand again.
+ * Whether a state-1 buffer was filled: tv_gemm_f32_last_form() != 0 after the call.
+ * No counterpart in the reference (its GEMMs are torch's); the shapes are those of
+ * tv_gemm_f32_act. */
+int tv_gemm_f32_ex(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
+                   int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc,
+                   const float *bias, const float *row_scale, int accumulate, int act_operand,
+                   const float *act_scale, const float *act_shift, float act_slope, float *a_max,
+                   int a_max_state, float *b_max, int b_max_state, void *workspace,
+                   int64_t workspace_bytes, void *stream);
 
 /* Linear layers with one small side, min(in_features, out_features) <= 16 - the z / z2 mean and
  * log-std heads (1000 -> 10) and the first layers fed by z (10 -> 500 / 250):

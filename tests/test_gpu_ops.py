@@ -1154,3 +1154,34 @@ def test_bn_lrelu_linear_equals_composition(device, rows, cols, out, weighted):
         res.append((ft.detach(), x.grad, g.grad, b.grad, w.grad, rm, rv))
     for i, name in enumerate(('ft', 'dx', 'dgamma', 'dbeta', 'dw', 'running_mean', 'running_var')):
         assert rel_err(res[0][i], res[1][i]) < 2e-5, name
+
+
+def test_gemm_operand_maxima_kept_by_the_caller(device):
+    """`tv_gemm_f32_ex`: the maxima a first product leaves in the caller's buffer (state 1) give
+    the later products of the same operand views (state 2) bit for bit what a scan of their own
+    gives, on both fp16 forms; a product on the bf16 form leaves the buffer unmarked."""
+    from tracevae_amd import hip, ops
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    rows, width = 33000, 1004
+    x = torch.randn(rows, 1000, generator=gen).to(device) * 3.0
+    w = (torch.randn(width, 1000, generator=gen) * 0.05).to(device)
+    dy = (torch.randn(rows, width, generator=gen) * 1e-4).to(device)
+    scale = (0.5 + torch.rand(1000, generator=gen)).to(device)
+    shift = (0.3 * torch.randn(1000, generator=gen)).to(device)
+    act1, act2 = (1, scale, shift, 0.01), (2, scale, shift, 0.01)
+    xm, wm, dm = ops.OperandMax(device), ops.OperandMax(device), ops.OperandMax(device)
+    ft = ops.gemm(x, w, False, True, act=act1, a_max=xm, b_max=wm)
+    assert hip.lib().tv_gemm_f32_last_form() == 1 and xm.valid and wm.valid
+    assert torch.equal(ft, ops.gemm(x, w, False, True, act=act1))
+    amax = float(torch.nn.functional.leaky_relu(x * scale + shift, 0.01).abs().max())
+    assert float(xm.slots.max()) == pytest.approx(amax, rel=1e-6)
+    assert float(wm.slots.max()) == float(w.abs().max())
+    dx = ops.gemm(dy, w, False, False, a_max=dm, b_max=wm)          # weights: state 2
+    assert dm.valid and torch.equal(dx, ops.gemm(dy, w, False, False))
+    dw = ops.gemm(dy, x, True, False, act=act2, a_max=dm, b_max=xm)  # both: state 2
+    assert hip.lib().tv_gemm_f32_last_form() == 2
+    assert torch.equal(dw, ops.gemm(dy, x, True, False, act=act2))
+    # the bf16 form (few rows) does not touch the buffers
+    sm = ops.OperandMax(device)
+    ops.gemm(x[:300], w, False, True, a_max=sm)
+    assert hip.lib().tv_gemm_f32_last_form() == 0 and not sm.valid

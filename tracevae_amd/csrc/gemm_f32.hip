@@ -2138,8 +2138,13 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
              int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, const float *bias,
              const float *row_scale, int accumulate, int act_operand, const float *act_scale,
              const float *act_shift, float act_slope, void *workspace, int64_t workspace_bytes,
-             void *stream) {
+             void *stream, float *a_max = nullptr, int a_max_state = 0, float *b_max = nullptr,
+             int b_max_state = 0) {
   TV_REQUIRE(m >= 0 && n >= 0 && k >= 0, "tv_gemm_f32: negative size");
+  TV_REQUIRE(a_max_state >= 0 && a_max_state <= 2 && b_max_state >= 0 && b_max_state <= 2 &&
+                 (a_max || a_max_state == 0) && (b_max || b_max_state == 0),
+             "tv_gemm_f32_ex: operand-maximum state must be 0 (none), 1 (compute into the buffer) "
+             "or 2 (the buffer is valid), with a buffer for 1 and 2");
   if (m == 0 || n == 0) return TV_OK;
   TV_REQUIRE(a && b && c, "tv_gemm_f32: null operand");
   TV_REQUIRE(lda >= (trans_a ? m : k), "tv_gemm_f32: lda %lld too small", (long long)lda);
@@ -2197,6 +2202,9 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     amax_a = (float *)((char *)workspace + plan.slab_bytes + plan.planes_bytes);
     amax_b = amax_a + AMAX_SLOTS;
   }
+  // caller-kept maxima (tv_gemm_f32_ex): computed into the caller's buffer, or taken from it
+  if (a_max_state) amax_a = a_max;
+  if (b_max_state) amax_b = b_max;
   // max |operand| of a row-major [rows][cols] operand (behind its prologue), 256 partial maxima
   auto launch_amax = [&](const float *x, int64_t ld, int64_t rows, int64_t cols, bool act, float *slots) {
     const int vec = (ld % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
@@ -2224,7 +2232,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     const dim3 sgrid((unsigned)(((g.tiles_n + 1) & ~1ll) * g.b_ktiles));
     if (take_wide) {
       // B as stored: [n][k] (trans_b) or [k][n]
-      launch_amax(b, ldb, trans_b ? n : k, trans_b ? k : n, false, amax_b);
+      if (b_max_state != 2) launch_amax(b, ldb, trans_b ? n : k, trans_b ? k : n, false, amax_b);
       TV_LAUNCH_CHECK("tv_gemm_f32(max of B)");
       hipLaunchKernelGGL(gemm_split_b_h_kernel, sgrid, dim3(256), 0, s, b, ldb, trans_b ? 0 : 1, n, k,
                          g.b_ktiles, (const float *)amax_b, planes);
@@ -2245,7 +2253,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     TV_REQUIRE(units < (1ll << 31), "tv_gemm_f32: grid too large");
     w.units = units;
     w.a_amax = amax_a; w.b_amax = amax_b;
-    launch_amax(a, lda, m, k, act_operand == 1, amax_a);
+    if (a_max_state != 2) launch_amax(a, lda, m, k, act_operand == 1, amax_a);
     TV_LAUNCH_CHECK("tv_gemm_f32(max of A)");
     // two plane buffers + the eight waves' output staging behind them
     const size_t wlds = 2 * (size_t)H_BUF_BYTES + 8 * 32 * 64 * sizeof(float);
@@ -2284,8 +2292,8 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     const int64_t units = plan.w_tiles * plan.km_splits;
     w.units = units;
     w.a_amax = amax_a; w.b_amax = amax_b;
-    launch_amax(a, lda, k, m, false, amax_a);                    // A stored [k][m]
-    launch_amax(b, ldb, k, n, act_operand == 2, amax_b);         // B stored [k][n]
+    if (a_max_state != 2) launch_amax(a, lda, k, m, false, amax_a);                    // A stored [k][m]
+    if (b_max_state != 2) launch_amax(b, ldb, k, n, act_operand == 2, amax_b);         // B stored [k][n]
     TV_LAUNCH_CHECK("tv_gemm_f32(max of the operands)");
     const size_t wlds = 2 * (size_t)H_BUF_BYTES;
     int device = 0;
@@ -2384,4 +2392,16 @@ extern "C" int tv_gemm_f32_act(int trans_a, int trans_b, int64_t m, int64_t n, i
                                int64_t workspace_bytes, void *stream) {
   return run_gemm(trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, row_scale, accumulate,
                   act_operand, act_scale, act_shift, act_slope, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tv_gemm_f32_ex(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k,
+                              const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
+                              int64_t ldc, const float *bias, const float *row_scale,
+                              int accumulate, int act_operand, const float *act_scale,
+                              const float *act_shift, float act_slope, float *a_max,
+                              int a_max_state, float *b_max, int b_max_state, void *workspace,
+                              int64_t workspace_bytes, void *stream) {
+  return run_gemm(trans_a, trans_b, m, n, k, a, lda, b, ldb, c, ldc, bias, row_scale, accumulate,
+                  act_operand, act_scale, act_shift, act_slope, workspace, workspace_bytes, stream,
+                  a_max, a_max_state, b_max, b_max_state);
 }

@@ -136,15 +136,33 @@ class DeviceGraph(object):
 # ---------------------------------------------------------------------------------------
 # dense
 # ---------------------------------------------------------------------------------------
+class OperandMax(object):
+    """The partial maxima of |operand| that the fp16 GEMM forms scale an operand by
+    (`tv_gemm_f32_ex`), kept by the caller so that a tensor entering several products is scanned
+    once.  One object per operand VIEW: same tensor, same rows and columns, same prologue."""
+    __slots__ = ['slots', 'valid']
+
+    def __init__(self, device):
+        self.slots = torch.empty([256], dtype=_f32, device=device)
+        self.valid = False
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
          bias: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, accumulate: bool = False,
-         act: Optional[tuple] = None) -> torch.Tensor:
-    """C = row_scale * (op(a) @ op(b)) + bias on the fp32 MFMA kernel (`tv_gemm_f32`).
+         act: Optional[tuple] = None, a_max: Optional[OperandMax] = None,
+         b_max: Optional[OperandMax] = None) -> torch.Tensor:
+    """C = row_scale * (op(a) @ op(b)) + bias on the matrix cores (`tv_gemm_f32_ex`).
     `act = (operand, scale, shift, slope)`: operand 1 (a, not transposed) or 2 (b, not
-    transposed) goes through lrelu(v * scale[f] + shift[f]) on its way into the kernel
-    (`tv_gemm_f32_act`)."""
+    transposed) goes through lrelu(v * scale[f] + shift[f]) on its way into the kernel.
+    `a_max` / `b_max`: see `OperandMax`."""
+    a_in, b_in = a, b
     a, b = _rows(a, 'a'), _rows(b, 'b')
+    # (maxima only travel with the caller's own view, not with a contiguous copy made here)
+    if a is not a_in:
+        a_max = None
+    if b is not b_in:
+        b_max = None
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     if not trans_a and k % 4 and a.stride(0) % 4 == 0 and a.stride(0) >= (k + 3) // 4 * 4:
         # the library reads such rows 16 bytes at a time, up to 3 floats past k (tracevae_hip.h):
@@ -167,25 +185,34 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
         return c
     wsb = hip.query('tv_gemm_f32_workspace_bytes', m, n, k)
     ws = _workspace(wsb, a.device)
+    operand, scale, shift, slope = act if act is not None else (0, None, None, 0.0)
+    if act is not None:
+        feats = k if operand == 1 else n
+        if scale.numel() != feats or shift.numel() != feats:
+            raise ValueError(f'gemm: act scale / shift must have {feats} entries')
+        scale, shift = _check(scale, 'act scale'), _check(shift, 'act shift')
     with TIMER.region('gemm_f32', 2.0 * m * n * k, (m, n, k, bool(trans_a), bool(trans_b))) as reg:
-        if act is None:
-            hip.call('tv_gemm_f32', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a), a.stride(0),
-                     hip.ptr_rows(b), b.stride(0), hip.ptr_rows(c), c.stride(0), hip.ptr(bias),
-                     hip.ptr(row_scale), int(accumulate), hip.ptr(ws), wsb)
-        else:
-            operand, scale, shift, slope = act
-            feats = k if operand == 1 else n
-            if scale.numel() != feats or shift.numel() != feats:
-                raise ValueError(f'gemm: act scale / shift must have {feats} entries')
-            hip.call('tv_gemm_f32_act', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a),
-                     a.stride(0), hip.ptr_rows(b), b.stride(0), hip.ptr_rows(c), c.stride(0), hip.ptr(bias),
-                     hip.ptr(row_scale), int(accumulate), int(operand),
-                     hip.ptr(_check(scale, 'act scale')), hip.ptr(_check(shift, 'act shift')),
-                     float(slope), hip.ptr(ws), wsb)
-        if reg is not None:
+        hip.call('tv_gemm_f32_ex', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a),
+                 a.stride(0), hip.ptr_rows(b), b.stride(0), hip.ptr_rows(c), c.stride(0), hip.ptr(bias),
+                 hip.ptr(row_scale), int(accumulate), int(operand), hip.ptr(scale), hip.ptr(shift),
+                 float(slope),
+                 None if a_max is None else a_max.slots.data_ptr(),
+                 0 if a_max is None else (2 if a_max.valid else 1),
+                 None if b_max is None else b_max.slots.data_ptr(),
+                 0 if b_max is None else (2 if b_max.valid else 1),
+                 hip.ptr(ws), wsb)
+        if reg is not None or a_max is not None or b_max is not None:
             # which arithmetic the product took: 0 = bf16 x 3 (six terms), 1 / 2 = fp16 x 2 (three
-            # terms) on the wide / k-major wide form; the bench prices each against its own peak
-            reg.tag = reg.tag + (int(hip.lib().tv_gemm_f32_last_form()),)
+            # terms) on the wide / k-major wide form; the bench prices each against its own peak,
+            # and only the fp16 forms fill the callers' operand maxima
+            form = int(hip.lib().tv_gemm_f32_last_form())
+            if reg is not None:
+                reg.tag = reg.tag + (form,)
+            if form:
+                if a_max is not None:
+                    a_max.valid = True
+                if b_max is not None:
+                    b_max.valid = True
     return c
 
 
@@ -273,7 +300,11 @@ class _LinearScores(Function):
         weight = _check(weight, 'weight')
         wx = gat_fc_score_weight(weight, attn_l, attn_r)
         ctx.save_for_backward(x2, weight, wx, attn_l, attn_r)
-        return gemm(x2, wx, False, True)
+        # x and the weights enter the backward pass's products again: their maxima are kept
+        need = any(ctx.needs_input_grad)
+        ctx.x_max = OperandMax(x2.device) if need else None
+        ctx.w_max = OperandMax(x2.device) if need else None
+        return gemm(x2, wx, False, True, a_max=ctx.x_max, b_max=ctx.w_max)
 
     @staticmethod
     @once_differentiable
@@ -281,10 +312,12 @@ class _LinearScores(Function):
         x2, weight, wx, attn_l, attn_r = ctx.saved_tensors
         dy = _check(dy, 'dy')
         dx = dw = dal = dar = None
+        dy_max = OperandMax(dy.device)
         if ctx.needs_input_grad[0]:
-            dx = gemm(dy, wx, False, False)
+            dx = gemm(dy, wx, False, False, a_max=dy_max, b_max=ctx.w_max)
         if any(ctx.needs_input_grad[1:]):
-            dw, dal, dar = _score_weight_grads(gemm(dy, x2, True, False), weight, attn_l, attn_r)
+            dw, dal, dar = _score_weight_grads(
+                gemm(dy, x2, True, False, a_max=dy_max, b_max=ctx.x_max), weight, attn_l, attn_r)
         return dx, dw, dal, dar
 
 
@@ -586,7 +619,11 @@ class _BNLReLULinear(Function):
         # with attention vectors: [ft | el | er], as `_LinearScores`
         ctx.scores = attn_l is not None
         w_fwd = gat_fc_score_weight(weight, attn_l, attn_r) if ctx.scores else weight
-        ft = gemm(x, w_fwd, False, True, act=(1, scale, shift, slope))
+        need = any(ctx.needs_input_grad)
+        ctx.x_max = OperandMax(dev) if need else None       # of lrelu(x * scale + shift)
+        ctx.w_max = OperandMax(dev) if need else None
+        ft = gemm(x, w_fwd, False, True, act=(1, scale, shift, slope), a_max=ctx.x_max,
+                  b_max=ctx.w_max)
         if ctx.scores:
             ctx.save_for_backward(x, coeffs, gamma, beta, weight, w_fwd, attn_l, attn_r)
         else:
@@ -606,12 +643,14 @@ class _BNLReLULinear(Function):
         mean, rstd, scale, shift = (coeffs[i, :cols] for i in range(4))
         dft = _check(dft, 'dft')           # with scores: [dft | del | der | 0]
         dx = dgamma = dbeta = dw = dal = dar = None
+        dft_max = OperandMax(dft.device)
         if ctx.needs_input_grad[3] or (ctx.scores and any(ctx.needs_input_grad[12:14])):
-            dw = gemm(dft, x, True, False, act=(2, scale, shift, ctx.slope))
+            dw = gemm(dft, x, True, False, act=(2, scale, shift, ctx.slope), a_max=dft_max,
+                      b_max=ctx.x_max)
             if ctx.scores:
                 dw, dal, dar = _score_weight_grads(dw, weight, attn_l, attn_r)
         if any(ctx.needs_input_grad[:3]):
-            dy = gemm(dft, w_fwd, False, False)
+            dy = gemm(dft, w_fwd, False, False, a_max=dft_max, b_max=ctx.w_max)
             dx = torch.empty_like(x)
             dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
             wsb = hip.query('tv_bn_lrelu_bwd_workspace_bytes', rows, cols)
