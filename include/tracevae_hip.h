@@ -267,6 +267,10 @@ int tv_colsum(int64_t rows, int64_t cols, const float *x, int64_t ldx, float *ou
  *   dweight_ext [H*F + pad4(2H), in] = [dft | del | der]^T x, and this call folds its derived rows
  *   back: dW += attn_l (x) dWx[H*F+h] + attn_r (x) dWx[H*F+H+h] (in place, rows 0..H*F-1),
  *   dattn_l[h,f] = <W[h*F+f], dWx[H*F+h]>.  The backward pass then does not read ft's rows again.
+ * out_max (forward, with the eval epilogue only) / dft_max (backward, with score_grad_columns
+ *   only), nullable: TV_GEMM_MAX_SLOTS floats that receive partial maxima of |out| / of the
+ *   whole [dft | del | der | 0] rows, for the product that reads those rows next
+ *   (tv_gemm_f32_ex, state 2); folded in with integer atomic max (order-free, deterministic).
  * Row strides (in floats) let the aggregation read that layout in place: `ft_stride` of ft
  *   (0 = H*F; a multiple of 4), `score_stride` of el / er (0 = H), `dft_stride` of dft (0 = H*F).
  * ---------------------------------------------------------------------------------- */
@@ -283,7 +287,7 @@ int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
                          const float *el, const float *er, const float *bias, float *out,
                          float *alpha, float *stats_partial, const float *stats_row_weight,
                          const float *ep_scale, const float *ep_shift, float ep_slope,
-                         int64_t ft_stride, int64_t score_stride, void *stream);
+                         int64_t ft_stride, int64_t score_stride, float *out_max, void *stream);
 int64_t tv_gat_aggregate_bwd_workspace_bytes(int64_t rows_per_rep, int64_t n_rep,
                                              int64_t heads, int64_t feats, int64_t num_edges);
 int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
@@ -292,8 +296,8 @@ int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
                          const float *attn_l, const float *attn_r, const float *alpha,
                          const float *dout, float *dft, float *dattn_l, float *dattn_r,
                          float *dbias, int64_t ft_stride, int64_t score_stride,
-                         int64_t dft_stride, int score_grad_columns, void *workspace,
-                         int64_t workspace_bytes, void *stream);
+                         int64_t dft_stride, int score_grad_columns, float *dft_max,
+                         void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm over rows + LeakyReLU (tk.layers.BatchNorm = torch BatchNorm1d, then
@@ -312,7 +316,12 @@ int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
  *                        count = rows, or the sum of row_weight when rows are weighted
  *   tv_affine_lrelu_bwd: dx = dy * lrelu'(x*scale+shift) * scale (eval mode inside a
  *                        training step: phase 2 of train.py:204-208)
- * ---------------------------------------------------------------------------------- */
+ * ----------------------------------------------------------------------------------  * act_max (tv_bn_finalize_coeffs, nullable, cols <= 2048): TV_GEMM_MAX_SLOTS floats that receive
+ * a bound on |LeakyReLU(x * scale + shift)| over the rows behind the statistics
+ * (|gamma| sqrt(count) + |beta| per column), for the product that applies these coefficients to
+ * its operand (tv_gemm_f32_ex, state 2); rows of weight 0 are not covered by it (the fp16 split
+ * saturates instead of overflowing).
+ */
 int tv_colstats(int64_t rows, int64_t cols, const float *x, const float *row_weight,
                 float *partial, void *stream);
 int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, int64_t count, float eps,
@@ -321,7 +330,8 @@ int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, int64_t cou
 int tv_bn_finalize_coeffs(int64_t cols, int64_t nblk, const float *partial, int64_t count,
                           float eps, float momentum, float *mean, float *rstd,
                           float *running_mean, float *running_var, const float *gamma,
-                          const float *beta, float *scale, float *shift, void *stream);
+                          const float *beta, float *scale, float *shift, float *act_max,
+                          void *stream);
 int tv_bn_apply_lrelu(int64_t rows, int64_t cols, const float *x, const float *mean,
                       const float *rstd, const float *gamma, const float *beta, float slope,
                       float *y, void *stream);

@@ -1185,3 +1185,61 @@ def test_gemm_operand_maxima_kept_by_the_caller(device):
     sm = ops.OperandMax(device)
     ops.gemm(x[:300], w, False, True, a_max=sm)
     assert hip.lib().tv_gemm_f32_last_form() == 0 and not sm.valid
+
+
+def test_operand_maxima_from_the_producing_kernels(device):
+    """The kernels that write a GEMM operand leave its maxima with it: the aggregation with the
+    eval epilogue (exact: the next layer's product is bit-equal to one that scans), the backward
+    aggregation (exact, over the whole [dft | del | der | 0] rows), and the BatchNorm finalize
+    (a bound: the product stays within the GEMM's error bound of the float64 result)."""
+    from tracevae_amd import hip, ops
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    from helpers import make_flat
+    V, M, H, F = 50, 40, 2, 500
+    flat, lr = make_flat(900, V, M, seed=3)
+    store = DeviceTraceStore(flat, lr, V)
+    batch = TraceGraphBatch.from_store(store, np.arange(len(flat)), M).build_dgl()
+    g = batch.dec                                     # 900 * 40 = 36000 rows: the wide GEMM form
+    gen = torch.Generator(device='cpu').manual_seed(1)
+    rnd = lambda *sh: torch.randn(*sh, generator=gen).to(device)
+    x = rnd(g.num_rows, 64)
+    w, al, ar, bias = 0.1 * rnd(H * F, 64), 0.1 * rnd(1, H, F), 0.1 * rnd(1, H, F), 0.1 * rnd(H * F)
+    w2 = 0.05 * rnd(H * F, H * F)
+    sc, sh = 0.5 + torch.rand(H * F, generator=gen).to(device), 0.2 * rnd(H * F)
+    with torch.no_grad():
+        ft = ops.linear_scores(x, w, al, ar)
+        out, _ = ops.gat_conv(ft, al, ar, bias, g, 1, ep_scale=sc, ep_shift=sh, ep_slope=0.01)
+        box = ops.operand_max(out)
+        assert box is not None and float(box.slots.max()) == float(out.abs().max())
+        before = dict(ops.OPERAND_SCANS)
+        y = ops.linear_scores(out, w2, al, ar)
+        assert hip.lib().tv_gemm_f32_last_form() == 1
+        assert ops.OPERAND_SCANS['kept'] == before['kept'] + 1           # out: kept; weights: scanned
+        assert torch.equal(y, ops.linear_scores(out.clone(), w2, al, ar))
+        out.add_(1.0)                                  # written to: the maxima no longer apply
+        assert ops.operand_max(out) is None
+    # backward: the gradient rows carry their maxima into the fc layer's two products
+    xg = x.clone().requires_grad_(True)
+    wg = w.clone().requires_grad_(True)
+    ft = ops.linear_scores(xg, wg, al, ar)
+    out, _ = ops.gat_conv(ft, al, ar, bias.clone().requires_grad_(True), g, 1)
+    dout = rnd(*out.shape)
+    before = dict(ops.OPERAND_SCANS)
+    out.backward(dout)
+    kept = ops.OPERAND_SCANS['kept'] - before['kept']
+    assert kept >= 2, (before, ops.OPERAND_SCANS)      # dft in the dx and dW products (+ x, weights)
+    # the BatchNorm bound against the float64 product
+    rows = 40000
+    xb = 3.0 * rnd(rows, H * F) + 1.0
+    gamma, beta = 0.5 + torch.rand(H * F, generator=gen).to(device), 0.3 * rnd(H * F)
+    rm, rv = torch.zeros(H * F, device=device), torch.ones(H * F, device=device)
+    before = dict(ops.OPERAND_SCANS)
+    got = ops.bn_lrelu_linear(xb, gamma, beta, w2, rm, rv, 1e-6)
+    assert hip.lib().tv_gemm_f32_last_form() == 1
+    assert ops.OPERAND_SCANS['kept'] == before['kept'] + 1               # x: the bound
+    xd = xb.double()
+    xhat = (xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + 1e-6)
+    act = torch.nn.functional.leaky_relu(xhat * gamma.double() + beta.double(), 0.01)
+    want = act @ w2.double().t()
+    scale = act.abs() @ w2.double().abs().t()
+    assert float(((got.double() - want).abs() / scale).max()) < 2e-6

@@ -139,6 +139,11 @@ struct AggArgs {
   float ep_slope;
   // backward
   float *dpre, *der, *dft, *partial;
+  // optional: 256 partial maxima of |out| (forward with the eval epilogue) or |dft row| (backward
+  // with score-gradient columns), kept for the fp16 GEMM forms that read those rows next
+  // (tv_gemm_f32_ex).  Workgroups fold their maximum in with an integer atomic max on the bits
+  // of the non-negative float: order-free, so the result is the same on every run.
+  float *out_max;
   // row strides in floats: ft (H*F dense; H*F + 2H when el / er are two more column groups of the
   // fc product, tv_gat_fc_score_weight), el / er (H dense), dft
   int64_t ld_ft, ld_e, ld_dft;
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd
 #pragma unroll
     for (int c = 0; c < CH; ++c) ssum[c] = ssq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float omax = 0.f;
 
   // A row costs a chain of dependent loads: indptr -> indices -> scores -> neighbour rows.  The
   // first two links are taken off the chain by looking ahead: (p0, deg) of the row after next
@@ -358,6 +364,7 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd
           o.y = tv_lrelu(fmaf(o.y, sc.y, sh.y), a.ep_slope);
           o.z = tv_lrelu(fmaf(o.z, sc.z, sh.z), a.ep_slope);
           o.w = tv_lrelu(fmaf(o.w, sc.w, sh.w), a.ep_slope);
+          omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
         // many replicas (K-sample scoring: gigabytes of output that no cache will hold for the
         // next kernel): stream the rows past the L2, which then keeps the gathered rows
@@ -377,6 +384,10 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd
 #pragma unroll
     for (int c = 0; c < CH; ++c) { v[0][c] = ssum[c]; v[1][c] = ssq[c]; }
     block_col_reduce<2, CH>(lds, v, c4, a.stats_partial + (int64_t)blockIdx.x * 2 * HF);
+  }
+  if (EPILOGUE && a.out_max) {
+    omax = tv_wave_max(omax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.out_max) + (blockIdx.x & 255), __float_as_uint(omax));
   }
 }
 
@@ -682,6 +693,7 @@ __global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
   float4 pb[CH];                                     // dbias = column sums of dout
 #pragma unroll
   for (int c = 0; c < CH; ++c) pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dmax = 0.f;
 
   for (int64_t r = rw.beg; r < rw.end; r += rw.step) {  // (a single replica: row = node)
     const int64_t p0 = a.indptr[r];
@@ -806,8 +818,16 @@ __global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int q = lane + 64 * c;
-      if (q < c4) orow[q] = acc[c];
+      if (q < c4) {
+        orow[q] = acc[c];
+        dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(acc[c].x), fabsf(acc[c].y))),
+                     fmaxf(fabsf(acc[c].z), fabsf(acc[c].w)));
+      }
     }
+  }
+  if (a.out_max) {
+    dmax = tv_wave_max(dmax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.out_max) + (blockIdx.x & 255), __float_as_uint(dmax));
   }
 
   float4 vb[1][CH];
@@ -843,17 +863,25 @@ __global__ __launch_bounds__(256) void gat_bwd_score_cols_kernel(AggArgs a) {
     del[h] += __shfl_xor(del[h], 1, 64);
     del[h] += __shfl_xor(del[h], 2, 64);
   }
-  if (!live) return;
-  float *o = a.dft + r * a.ld_dft + (int64_t)H * a.F;
-  const int ncol = (2 * H + 3) & ~3;
-  for (int c = k; c < ncol; c += 4) {                // lane k writes columns k, k + 4, ...
-    float v = 0.f;
+  float vmax = 0.f;
+  if (live) {
+    float *o = a.dft + r * a.ld_dft + (int64_t)H * a.F;
+    const int ncol = (2 * H + 3) & ~3;
+    for (int c = k; c < ncol; c += 4) {              // lane k writes columns k, k + 4, ...
+      float v = 0.f;
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h) {
-      if (c == h && h < H) v = del[h];
-      if (c == H + h && h < H) v = a.der[r * H + h];
+      for (int h = 0; h < MAXH; ++h) {
+        if (c == h && h < H) v = del[h];
+        if (c == H + h && h < H) v = a.der[r * H + h];
+      }
+      o[c] = v;
+      vmax = fmaxf(vmax, fabsf(v));
     }
-    o[c] = v;
+  }
+  if (a.out_max) {
+    vmax = tv_wave_max(vmax);
+    if ((threadIdx.x & 63) == 0)
+      atomicMax(reinterpret_cast<unsigned *>(a.out_max) + (blockIdx.x & 255), __float_as_uint(vmax));
   }
 }
 
@@ -1047,8 +1075,10 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
                                     const float *bias, float *out, float *alpha,
                                     float *stats_partial, const float *stats_row_weight,
                                     const float *ep_scale, const float *ep_shift, float ep_slope,
-                                    int64_t ft_stride, int64_t score_stride, void *stream) {
+                                    int64_t ft_stride, int64_t score_stride, float *out_max,
+                                    void *stream) {
   if (int rc = check_shape("tv_gat_aggregate_fwd", rows_per_rep, n_rep, heads, feats)) return rc;
+  TV_REQUIRE(!out_max || ep_scale, "tv_gat_aggregate_fwd: out_max goes with the eval epilogue");
   if (int rc = check_strides("tv_gat_aggregate_fwd", heads, feats, ft, &ft_stride, &score_stride)) return rc;
   const int64_t rows = rows_per_rep * n_rep;
   if (rows == 0) return TV_OK;
@@ -1066,6 +1096,8 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   a.row_weight = stats_row_weight;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.ep_slope = ep_slope;
   a.ld_ft = ft_stride; a.ld_e = score_stride;
+  a.out_max = out_max;
+  if (out_max) TV_HIP(hipMemsetAsync(out_max, 0, 256 * sizeof(float), (hipStream_t)stream));
   // num_edges of one replica is only needed to index alpha; read back is avoided by
   // passing it through indptr on the host side of the caller: alpha is indexed with
   // rep * num_edges, and num_edges = indptr[rows_per_rep] is a device value.  With one
@@ -1113,9 +1145,11 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
                                     const float *attn_r, const float *alpha, const float *dout,
                                     float *dft, float *dattn_l, float *dattn_r, float *dbias,
                                     int64_t ft_stride, int64_t score_stride, int64_t dft_stride,
-                                    int score_grad_columns, void *workspace,
+                                    int score_grad_columns, float *dft_max, void *workspace,
                                     int64_t workspace_bytes, void *stream) {
   if (int rc = check_shape("tv_gat_aggregate_bwd", rows_per_rep, n_rep, heads, feats)) return rc;
+  TV_REQUIRE(!dft_max || score_grad_columns,
+             "tv_gat_aggregate_bwd: dft_max goes with the score-gradient columns");
   if (int rc = check_strides("tv_gat_aggregate_bwd", heads, feats, ft, &ft_stride, &score_stride)) return rc;
   if (dft_stride == 0) dft_stride = heads * feats;
   TV_REQUIRE(!score_grad_columns || dft_stride >= heads * feats + ((2 * heads + 3) & ~3ll),
@@ -1149,6 +1183,8 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   a.partial = a.der + pad4(rows * heads);
   TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gat_aggregate_bwd: workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  a.out_max = dft_max;
+  if (dft_max) TV_HIP(hipMemsetAsync(dft_max, 0, 256 * sizeof(float), s));
   const bool big = a.c4 > 256;
   const dim3 grid((unsigned)nblk), block(64 * TV_STAT_WAVES);
   if (score_grad_columns) {

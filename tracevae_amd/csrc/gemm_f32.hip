@@ -1363,7 +1363,12 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 // two elements -> their packed head and (scaled) residual halves
+// (the head saturates at the largest fp16 instead of overflowing: an operand maximum handed in by
+// the caller may be a bound that rows outside its statistics exceed, and a finite wrong value in
+// a row nobody reads is harmless where an infinity is not: inf - inf = NaN in the residual)
 __device__ __forceinline__ void split_f16(float a, float b, unsigned &head, unsigned &res) {
+  a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+  b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
   head = pack_f16(a, b);
   const f32x2v h = __builtin_convertvector(__builtin_bit_cast(f16x2, head), f32x2v);
   res = pack_f16((a - h[0]) * 2048.f, (b - h[1]) * 2048.f);

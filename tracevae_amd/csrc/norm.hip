@@ -35,10 +35,27 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int64_t C, int64_t nbl
                                                           float *running_mean,
                                                           float *running_var,
                                                           const float *gamma, const float *beta,
-                                                          float *scale, float *shift) {
+                                                          float *scale, float *shift,
+                                                          float *act_max) {
   const int64_t col = (int64_t)blockIdx.x * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
   double tot[2];
   tv_slot_sums<2>(partial, nblk, 2 * C, C, col, col < C, tot);
+  if (act_max) {
+    // a bound on |gamma * xhat + beta| over the rows that entered the statistics, for the fp16
+    // GEMM forms that apply this BatchNorm + LeakyReLU to their operand (tv_gemm_f32_ex, state
+    // 2): sum_r w_r (x_r - mean)^2 = count * var and every weight is >= 1, so |xhat| <=
+    // sqrt(count); |lrelu(y)| <= |y|.  Loose (sqrt(count) against the ~5 sigma of real data: 5-6
+    // binades of the 29 the fp16 split has to spare), but it costs no pass over the rows.  One
+    // slot per workgroup (at most 256 of them: C <= 2048), the rest zero.
+    float b = 0.f;
+    if (threadIdx.x < TV_SLOT_COLS && col < C) b = fabsf(gamma[col]) * (float)sqrt(count) + fabsf(beta[col]);
+    if (threadIdx.x < 64) {
+      b = tv_wave_max(b);
+      if (threadIdx.x == 0) act_max[blockIdx.x] = b;
+    }
+    if (blockIdx.x == 0)
+      for (int sl = (int)gridDim.x + threadIdx.x; sl < 256; sl += 256) act_max[sl] = 0.f;
+  }
   if (threadIdx.x >= TV_SLOT_COLS || col >= C) return;
   const double m = tot[0] / count;
   double var = tot[1] / count - m * m;
@@ -290,7 +307,7 @@ extern "C" int tv_bn_finalize(int64_t cols, int64_t nblk, const float *partial, 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(tv_slot_grid(cols)), dim3(256), 0,
                      (hipStream_t)stream, cols, nblk, partial, (double)count, eps, momentum, mean,
                      rstd, running_mean, running_var, (const float *)nullptr,
-                     (const float *)nullptr, (float *)nullptr, (float *)nullptr);
+                     (const float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
   TV_LAUNCH_CHECK("tv_bn_finalize");
   return TV_OK;
 }
@@ -299,15 +316,17 @@ extern "C" int tv_bn_finalize_coeffs(int64_t cols, int64_t nblk, const float *pa
                                      int64_t count, float eps, float momentum, float *mean,
                                      float *rstd, float *running_mean, float *running_var,
                                      const float *gamma, const float *beta, float *scale,
-                                     float *shift, void *stream) {
+                                     float *shift, float *act_max, void *stream) {
   TV_REQUIRE(cols >= 1 && nblk >= 1 && count >= 1, "tv_bn_finalize_coeffs: bad sizes");
+  TV_REQUIRE(!act_max || tv_slot_grid(cols) <= 256,
+             "tv_bn_finalize_coeffs: act_max takes at most 2048 columns");
   TV_REQUIRE(partial && mean && rstd && gamma && beta && scale && shift,
              "tv_bn_finalize_coeffs: null pointer");
   TV_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
              "tv_bn_finalize_coeffs: running_mean and running_var go together");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(tv_slot_grid(cols)), dim3(256), 0,
                      (hipStream_t)stream, cols, nblk, partial, (double)count, eps, momentum, mean,
-                     rstd, running_mean, running_var, gamma, beta, scale, shift);
+                     rstd, running_mean, running_var, gamma, beta, scale, shift, act_max);
   TV_LAUNCH_CHECK("tv_bn_finalize_coeffs");
   return TV_OK;
 }

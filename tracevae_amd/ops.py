@@ -140,11 +140,32 @@ class OperandMax(object):
     """The partial maxima of |operand| that the fp16 GEMM forms scale an operand by
     (`tv_gemm_f32_ex`), kept by the caller so that a tensor entering several products is scanned
     once.  One object per operand VIEW: same tensor, same rows and columns, same prologue."""
-    __slots__ = ['slots', 'valid']
+    __slots__ = ['slots', 'valid', 'version']
 
     def __init__(self, device):
         self.slots = torch.empty([256], dtype=_f32, device=device)
         self.valid = False
+        self.version = None
+
+    def attach(self, t: torch.Tensor) -> torch.Tensor:
+        """A producer kernel has written the maxima of `t`: they travel with the tensor object
+        (`operand_max(t)` finds them) for as long as nothing writes into it."""
+        self.valid = True
+        self.version = t._version
+        t.tv_operand_max = self
+        return t
+
+
+def operand_max(t: torch.Tensor) -> Optional[OperandMax]:
+    """The maxima a producer kernel left with this very tensor object, if it has not been written
+    to since; None otherwise (the product then scans the operand itself)."""
+    box = getattr(t, 'tv_operand_max', None)
+    if box is not None and box.valid and box.version == t._version:
+        return box
+    return None
+
+
+OPERAND_SCANS = {'kept': 0, 'scanned': 0}
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
@@ -191,6 +212,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
         if scale.numel() != feats or shift.numel() != feats:
             raise ValueError(f'gemm: act scale / shift must have {feats} entries')
         scale, shift = _check(scale, 'act scale'), _check(shift, 'act shift')
+    had = (a_max is not None and a_max.valid, b_max is not None and b_max.valid)
     with TIMER.region('gemm_f32', 2.0 * m * n * k, (m, n, k, bool(trans_a), bool(trans_b))) as reg:
         hip.call('tv_gemm_f32_ex', int(trans_a), int(trans_b), m, n, k, hip.ptr_rows(a),
                  a.stride(0), hip.ptr_rows(b), b.stride(0), hip.ptr_rows(c), c.stride(0), hip.ptr(bias),
@@ -213,6 +235,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool,
                     a_max.valid = True
                 if b_max is not None:
                     b_max.valid = True
+                # operands whose maxima were at hand / that the product had to scan
+                OPERAND_SCANS['kept'] += int(had[0]) + int(had[1])
+                OPERAND_SCANS['scanned'] += 2 - int(had[0]) - int(had[1])
     return c
 
 
@@ -302,7 +327,7 @@ class _LinearScores(Function):
         ctx.save_for_backward(x2, weight, wx, attn_l, attn_r)
         # x and the weights enter the backward pass's products again: their maxima are kept
         need = any(ctx.needs_input_grad)
-        ctx.x_max = OperandMax(x2.device) if need else None
+        ctx.x_max = (operand_max(x) if x2 is x else None) or (OperandMax(x2.device) if need else None)
         ctx.w_max = OperandMax(x2.device) if need else None
         return gemm(x2, wx, False, True, a_max=ctx.x_max, b_max=ctx.w_max)
 
@@ -310,9 +335,10 @@ class _LinearScores(Function):
     @once_differentiable
     def backward(ctx, dy):
         x2, weight, wx, attn_l, attn_r = ctx.saved_tensors
+        dy_in = dy
         dy = _check(dy, 'dy')
         dx = dw = dal = dar = None
-        dy_max = OperandMax(dy.device)
+        dy_max = (operand_max(dy_in) if dy is dy_in else None) or OperandMax(dy.device)
         if ctx.needs_input_grad[0]:
             dx = gemm(dy, wx, False, False, a_max=dy_max, b_max=ctx.w_max)
         if any(ctx.needs_input_grad[1:]):
@@ -471,13 +497,19 @@ class _GATConv(Function):
         # out once, the CSC arrays once, the attention coefficients out once when they are kept
         compulsory = 4.0 * (ft.stride(0) + hf) * rows + 8.0 * (graph.num_edges + graph.num_rows) \
             + (4.0 * heads * graph.num_edges if need_grad else 0.0)
+        # with the eval epilogue `out` is the next layer's operand as it stands: its maxima come
+        # out of this pass (`gat_conv` attaches them to the tensor it returns)
+        ctx.out_max = OperandMax(dev) if ep_scale is not None else None
         with TIMER.region('gat_aggregate_fwd', work, compulsory):
             hip.call('tv_gat_aggregate_fwd', graph.num_rows, n_rep, heads, feats,
                      hip.ptr(graph.indptr), hip.ptr(graph.indices), hip.ptr(ft), hip.ptr_rows(el),
                      hip.ptr_rows(er), hip.ptr(bias), hip.ptr(out), hip.ptr(alpha), hip.ptr(stats),
                      hip.ptr(stats_row_weight if want_stats else None),
                      hip.ptr(ep_scale), hip.ptr(ep_shift), float(ep_slope),
-                     ft.stride(0), el.stride(0))
+                     ft.stride(0), el.stride(0),
+                     None if ctx.out_max is None else ctx.out_max.slots.data_ptr())
+        if ctx.out_max is not None:
+            _LAST_OUT_MAX['box'] = ctx.out_max      # handed to `gat_conv`, which owns the tensor
         if need_grad:
             ctx.save_for_backward(ft, el, er, alpha, al, ar)
             ctx.graph = graph
@@ -519,12 +551,16 @@ class _GATConv(Function):
         # compulsory bytes: dout and ft rows in once, dft rows out once, coefficients and CSC / rev
         compulsory = 4.0 * (hf + 2 * ft.stride(0)) * g.num_rows + 4.0 * heads * g.num_edges \
             + 8.0 * (2 * g.num_edges + g.num_rows)
+        dft_max = OperandMax(dev) if cols else None
         with TIMER.region('gat_aggregate_bwd', work, compulsory):
             hip.call('tv_gat_aggregate_bwd', g.num_rows, 1, heads, feats, g.num_edges,
                      hip.ptr(g.indptr), hip.ptr(g.indices), hip.ptr(g.rev), hip.ptr(ft),
                      hip.ptr_rows(el), hip.ptr_rows(er), hip.ptr(al), hip.ptr(ar), hip.ptr(alpha),
                      hip.ptr(dout), hip.ptr(dft), hip.ptr(dal), hip.ptr(dar), hip.ptr(dbias),
-                     ft.stride(0), el.stride(0), dft.stride(0), int(cols), hip.ptr(ws), wsb)
+                     ft.stride(0), el.stride(0), dft.stride(0), int(cols),
+                     None if dft_max is None else dft_max.slots.data_ptr(), hip.ptr(ws), wsb)
+        if dft_max is not None:
+            dft_max.attach(dft)       # the fc layer's two products find it on the gradient tensor
         if not cols:
             dal, dar = dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape)
         return (dft, dal, dar, dbias, None, None, None, None, None, None, None, None)
@@ -540,8 +576,15 @@ def gat_conv(ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int = 1,
     # attention coefficients must be kept for a backward pass)
     need_grad = torch.is_grad_enabled() and any(
         t.requires_grad for t in (ft, attn_l, attn_r, bias))
-    return _GATConv.apply(ft, attn_l, attn_r, bias, graph, n_rep, want_stats, ep_scale, ep_shift,
-                          ep_slope, need_grad, stats_row_weight)
+    out, stats = _GATConv.apply(ft, attn_l, attn_r, bias, graph, n_rep, want_stats, ep_scale,
+                                ep_shift, ep_slope, need_grad, stats_row_weight)
+    box = _LAST_OUT_MAX.pop('box', None)
+    if box is not None:
+        box.attach(out)
+    return out, stats
+
+
+_LAST_OUT_MAX = {}
 
 
 # ---------------------------------------------------------------------------------------
@@ -612,15 +655,19 @@ class _BNLReLULinear(Function):
         # mean, rstd, scale, shift; rows padded so that each starts 16-byte aligned
         coeffs = torch.empty([4, (cols + 3) // 4 * 4], dtype=_f32, device=dev)
         mean, rstd, scale, shift = (coeffs[i, :cols] for i in range(4))
+        # (the finalize kernel also leaves a bound on |lrelu(x * scale + shift)| for the products
+        # that apply these coefficients to x: no pass over x for its maximum, forward or backward)
+        ctx.x_max = OperandMax(dev)
+        bound_ok = cols <= 2048
         hip.call('tv_bn_finalize_coeffs', cols, stats.shape[0], hip.ptr(stats), count, float(eps),
                  float(momentum), hip.ptr(mean), hip.ptr(rstd), hip.ptr(running_mean),
                  hip.ptr(running_var), hip.ptr(gamma), hip.ptr(beta), hip.ptr(scale),
-                 hip.ptr(shift))
+                 hip.ptr(shift), ctx.x_max.slots.data_ptr() if bound_ok else None)
+        ctx.x_max.valid = bound_ok
         # with attention vectors: [ft | el | er], as `_LinearScores`
         ctx.scores = attn_l is not None
         w_fwd = gat_fc_score_weight(weight, attn_l, attn_r) if ctx.scores else weight
         need = any(ctx.needs_input_grad)
-        ctx.x_max = OperandMax(dev) if need else None       # of lrelu(x * scale + shift)
         ctx.w_max = OperandMax(dev) if need else None
         ft = gemm(x, w_fwd, False, True, act=(1, scale, shift, slope), a_max=ctx.x_max,
                   b_max=ctx.w_max)
@@ -641,9 +688,10 @@ class _BNLReLULinear(Function):
             w_fwd, attn_l, attn_r = ctx.saved_tensors[5:]
         rows, cols = x.shape
         mean, rstd, scale, shift = (coeffs[i, :cols] for i in range(4))
+        dft_in = dft
         dft = _check(dft, 'dft')           # with scores: [dft | del | der | 0]
         dx = dgamma = dbeta = dw = dal = dar = None
-        dft_max = OperandMax(dft.device)
+        dft_max = (operand_max(dft_in) if dft is dft_in else None) or OperandMax(dft.device)
         if ctx.needs_input_grad[3] or (ctx.scores and any(ctx.needs_input_grad[12:14])):
             dw = gemm(dft, x, True, False, act=(2, scale, shift, ctx.slope), a_max=dft_max,
                       b_max=ctx.x_max)
