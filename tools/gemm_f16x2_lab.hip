@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -172,6 +173,141 @@ __global__ __launch_bounds__(512) void gemm_f16x2_kernel(const char *A, const ch
   }
 }
 
+// ONE multiplying wave per SIMD (256 threads, 512 registers per lane), a 128 x 64 block per wave,
+// 256 x 128 tile, both operands as ready-made fp16 plane images by LDS-DMA: 24 ds_read_b128 feed
+// 48 matrix instructions per wave and k-tile (0.5 per instruction; the 64 x 64 blocks above:
+// 0.67), and the workgroup reads 96 KB of LDS per k-tile instead of 128.  Reads of one k-step are
+// issued under the matrix instructions of the other; the barrier sits between the two k-steps.
+__global__ __launch_bounds__(256) void gemm_f16x2_big_kernel(const char *A, const char *B, float *C, int64_t M,
+                                                             int64_t N, int64_t ldc, int tiles_m, int tiles_n,
+                                                             int ktiles, float inv_scale) {
+  extern __shared__ __align__(16) char smem[];        // 2 x (B image | A image 0 | A image 1)
+  constexpr int BUF_BYTES = 3 * OPERAND_BYTES;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = (tiles_m / 2) * tiles_n;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int per = ntiles >> 3;
+    const int L = (tile & 7) * per + (tile >> 3);
+    const int tn = L % tiles_n, tm = L / tiles_n;
+    const char *a_img = A + (int64_t)(2 * tm) * ktiles * OPERAND_BYTES;
+    const char *b_img = B + (int64_t)tn * ktiles * OPERAND_BYTES;
+    const int64_t as = (int64_t)ktiles * OPERAND_BYTES;
+    f32x16 hi[4][2], lo[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+    f16x8 X0[4][2], Y0[2][2], X1[4][2], Y1[2][2];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned dma_voff = (unsigned)(wave * 4 * 1024 + lane * 16), dma_loff = (unsigned)(wave * 4 * 1024);
+    auto one_read = [&](auto rc, const char *buf, int step, f16x8 (&X)[4][2], f16x8 (&Y)[2][2]) {
+      constexpr int R = decltype(rc)::value, SET = R / 2, PL = R % 2;
+      if constexpr (SET < 2) {
+        const char *p = buf + plane_offset(wn * 64 + 32 * SET + (lane & 31), 2 * (2 * step + (lane >> 5)));
+        Y[SET][PL] = *reinterpret_cast<const f16x8 *>(p + PL * PLANE_BYTES);
+      } else {
+        const char *p = buf + (1 + wm) * OPERAND_BYTES +
+                        plane_offset(32 * (SET - 2) + (lane & 31), 2 * (2 * step + (lane >> 5)));
+        X[SET - 2][PL] = *reinterpret_cast<const f16x8 *>(p + PL * PLANE_BYTES);
+      }
+    };
+    auto one_mfma = [&](auto kc, f16x8 (&X)[4][2], f16x8 (&Y)[2][2]) {
+      constexpr int K = decltype(kc)::value, BLK = K / 3, TERM = K % 3, I = BLK >> 1;
+      constexpr int J = (I & 1) ? 1 - (BLK & 1) : (BLK & 1);
+      if constexpr (TERM == 0) lo[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[I][1], Y[J][0], lo[I][J], 0, 0, 0);
+      else if constexpr (TERM == 1) lo[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[I][0], Y[J][1], lo[I][J], 0, 0, 0);
+      else hi[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[I][0], Y[J][0], hi[I][J], 0, 0, 0);
+    };
+    auto one_dma = [&](auto qc, int kt, char *buf) {
+      constexpr int Q = decltype(qc)::value, IMG = Q / 4, CH = Q % 4;
+      const char *src = (IMG == 0 ? b_img : a_img + (int64_t)(IMG - 1) * as) + (int64_t)kt * OPERAND_BYTES;
+      __builtin_amdgcn_global_load_lds((const void *)(src + dma_voff + CH * 1024),
+                                       (lds_void *)(buf + IMG * OPERAND_BYTES + dma_loff + CH * 1024), 16, 0, 0);
+    };
+    // one k-step: 24 matrix instructions on (Xm, Ym) with the 12 reads of the other k-step's
+    // fragments (and, when DMA, the 12 DMAs of the tile after next) dealt out between them
+    auto kstep = [&](auto dmac, f16x8 (&Xm)[4][2], f16x8 (&Ym)[2][2], const char *rbuf, int rstep,
+                     f16x8 (&Xr)[4][2], f16x8 (&Yr)[2][2], int kt, char *dbuf) {
+      constexpr bool DMA = decltype(dmac)::value;
+      auto group = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        one_read(qc, rbuf, rstep, Xr, Yr);
+        one_mfma(std::integral_constant<int, 2 * Q>(), Xm, Ym);
+        if constexpr (DMA) one_dma(qc, kt, dbuf);
+        one_mfma(std::integral_constant<int, 2 * Q + 1>(), Xm, Ym);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      group(std::integral_constant<int, 0>()); group(std::integral_constant<int, 1>());
+      group(std::integral_constant<int, 2>()); group(std::integral_constant<int, 3>());
+      group(std::integral_constant<int, 4>()); group(std::integral_constant<int, 5>());
+      group(std::integral_constant<int, 6>()); group(std::integral_constant<int, 7>());
+      group(std::integral_constant<int, 8>()); group(std::integral_constant<int, 9>());
+      group(std::integral_constant<int, 10>()); group(std::integral_constant<int, 11>());
+    };
+    auto frags = [&](const char *buf, int step, f16x8 (&X)[4][2], f16x8 (&Y)[2][2]) {
+      const char *As = buf + (1 + wm) * OPERAND_BYTES;
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) read_set(buf, wn * 64 + 32 * j2, lane, step, Y[j2]);
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) read_set(As, 32 * i2, lane, step, X[i2]);
+    };
+    auto multiply = [&](f16x8 (&X)[4][2], f16x8 (&Y)[2][2]) {
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) mma3(X[i2], Y[(i2 & 1) ? 1 - j2 : j2], hi[i2][(i2 & 1) ? 1 - j2 : j2], lo[i2][(i2 & 1) ? 1 - j2 : j2]);
+    };
+    auto stage3 = [&](int kt, char *buf) {
+#pragma unroll
+      for (int img = 0; img < 3; ++img) {
+        const char *src = (img == 0 ? b_img : a_img + (int64_t)(img - 1) * as) + (int64_t)kt * OPERAND_BYTES;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          __builtin_amdgcn_global_load_lds((const void *)(src + dma_voff + c * 1024),
+                                           (lds_void *)(buf + img * OPERAND_BYTES + dma_loff + c * 1024), 16, 0, 0);
+      }
+    };
+    __builtin_amdgcn_s_barrier();
+    stage3(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ktiles > 1) stage3(1, smem + BUF_BYTES);
+    frags(smem, 0, X0, Y0);
+    for (int it = 0; it + 1 < ktiles; ++it) {
+      char *cur = smem + (it & 1) * BUF_BYTES, *nxt = smem + ((it + 1) & 1) * BUF_BYTES;
+      const int kt = it + 2 < ktiles ? it + 2 : ktiles - 1;
+      kstep(std::false_type(), X0, Y0, cur, 1, X1, Y1, 0, nullptr);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      kstep(std::true_type(), X1, Y1, nxt, 0, X0, Y0, kt, cur);
+    }
+    {
+      char *cur = smem + ((ktiles - 1) & 1) * BUF_BYTES;
+      kstep(std::false_type(), X0, Y0, cur, 1, X1, Y1, 0, nullptr);
+      multiply(X1, Y1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int kh = lane >> 5, xl = lane & 31;
+    const int64_t m0 = (int64_t)tm * 2 * BM, n0 = (int64_t)tn * BN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 32 + xl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * 128 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+          if (row < M && col < N) C[row * ldc + col] = (hi[i][j][r] + lo[i][j][r] * (1.f / 2048.f)) * inv_scale;
+        }
+      }
+  }
+}
+
 int main(int argc, char **argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 51200, N = argc > 2 ? atoll(argv[2]) : 1024;
   const int64_t K = argc > 3 ? atoll(argv[3]) : 1024;
@@ -224,6 +360,26 @@ int main(int argc, char **argv) {
   run(gemm_f16x2_kernel<1, 2>, "f16x2 128x256, 8 waves, 2 buffers, persistent", 2, 1);
   run(gemm_f16x2_kernel<0, 3>, "f16x2 128x256, 8 waves, 3 buffers", 3, 0);
   run(gemm_f16x2_kernel<1, 3>, "f16x2 128x256, 8 waves, 3 buffers, persistent", 3, 1);
+  if (tiles_m % 2 == 0 && ((tiles_m / 2) * tiles_n) % 8 == 0) {
+    const size_t lds = 2 * 3 * (size_t)OPERAND_BYTES;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16x2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int persist = 0; persist < 2; ++persist) {
+      const int grid = persist ? 256 : (tiles_m / 2) * tiles_n;
+      CHECK(hipMemset(dC, 0, (size_t)M * N * 4));
+      for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL(gemm_f16x2_big_kernel, dim3(grid), dim3(256), lds, 0, pA, pB, dC, M, N, N, tiles_m, tiles_n, ktiles, inv);
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipEventRecord(e0));
+      for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(gemm_f16x2_big_kernel, dim3(grid), dim3(256), lds, 0, pA, pB, dC, M, N, N, tiles_m, tiles_n, ktiles, inv);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+      printf("%-52s %lld x %lld x %lld  %.3f ms  %.1f TF (algorithmic)\n",
+             persist ? "f16x2 256x128, 4 waves of 128x64, persistent" : "f16x2 256x128, 4 waves of 128x64",
+             (long long)M, (long long)N, (long long)K, ms, 2.0 * M * N * K / ms / 1e9);
+    }
+  }
   std::vector<float> hc((size_t)M * N);
   CHECK(hipMemcpy(hc.data(), dC, hc.size() * 4, hipMemcpyDeviceToHost));
   double worst = 0, worst32 = 0;

@@ -49,7 +49,7 @@ def per_kernel(path, counter):
     return out
 
 
-def traffic(fetch_csv, write_csv, dst, family=('gemm_kernel', 'gemm_wide_kernel', 'gemm_kmajor_wide_kernel')):
+def traffic(fetch_csv, write_csv, dst, family=('gemm_kernel', 'gemm_wide_h_kernel', 'gemm_kmajor_wide_h_kernel')):
     f = per_kernel(fetch_csv, 'FETCH_SIZE')
     w = per_kernel(write_csv, 'WRITE_SIZE')
     kernels = {}

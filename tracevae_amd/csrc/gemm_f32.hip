@@ -2,6 +2,15 @@
 //
 //   C[M,N] = row_scale[m] * (op(A)[M,K] . op(B)[K,N]) + bias[n]
 //
+// Two arithmetic forms, chosen by shape (run_gemm):
+//   * the WIDE forms (128 x 256 tiles: the layer products and weight gradients of many rows, which
+//     carry the time) split every element into two fp16 planes under a power-of-two operand
+//     scale and issue three matrix instructions per product - described where they are defined,
+//     "The two wide forms on TWO fp16 planes";
+//   * every other shape runs on the producer / consumer kernel below, on three bf16 planes and
+//     six matrix instructions per product, which needs no scale.  The rest of this header is about
+//     that form.
+//
 // Every fp32 operand element is split into three bf16 planes x = x0 + x1 + x2 (round-to-nearest
 // at each level: 8 + 8 + 8 mantissa bits), and the six partial products of weight >= 2^-16,
 //     a0 b0 | a0 b1 + a1 b0 | a0 b2 + a1 b1 + a2 b0,
@@ -12,8 +21,7 @@
 // 1000 times in an fp32 fma chain).  Measured on MI355X against float64 the result is 2-4x
 // CLOSER than the exact-fp32 MFMA chain on normal, wide-dynamic-range, cancelling and
 // all-positive data (tools/bf16x3_numerics.hip; tests/test_gpu_ops.py holds the bound against
-// an fp32 GEMM; the dropped terms a1 b2, a2 b1, a2 b2 are below 2^-24 relative).  There is no
-// three-term variant and no other precision: this is the one GEMM of the library.  An infinite
+// an fp32 GEMM; the dropped terms a1 b2, a2 b1, a2 b2 are below 2^-24 relative).  An infinite
 // operand gives NaN (inf - inf in the split) where an fp32 chain gives inf; NaN stays NaN.
 //
 // Tiling: 128x128 output tile, BK = 32, one 512-thread workgroup per CU:
@@ -754,326 +762,22 @@ __global__ __launch_bounds__(512) void gemm_kernel(GemmArgs g) {
 
 // ------------------------------------------------------------------------------------------
 // The wide form: the layer products that carry the time (many rows of a row-major A against a
-// small pre-split B: forward products and input gradients).
+// small pre-split B: forward products and input gradients).  Its kernel, gemm_wide_h_kernel, is
+// further down with the fp16 arithmetic it runs on; the shape of it:
 //
-// 128 x 256 output tile, 512 threads = EIGHT waves that all multiply (2 x 4, a 64x64 block each,
-// the same 48 matrix instructions and 24 ds_read_b128 per k-tile as above), two per SIMD: while one
-// wave waits for its fragments or at the barrier the other keeps the matrix pipe busy.  B's two
-// plane images come global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write,
-// no vector ALU), A is split by the multiplying waves themselves between their matrix
-// instructions: 8 elements per thread and k-tile (two 16-byte loads, ~44 vector instructions,
-// three ds_write_b128).  Two LDS buffers of 72 KB, one barrier per k-tile, loads and DMAs counted
-// by hand (inline assembly: beside LDS-DMA in flight the compiler drains every load before a
-// ds_write of its own).  tools/gemm_planes_lab.hip measured the form first: 200 TF on
-// 51200 x 1024 x 1024 against 177 for four multiplying waves fed by four producer waves.
-// The output leaves straight from the accumulators (128-byte row segments per half-wave): no LDS
-// is left for a staged tile, and the two waves of a SIMD overlap each other's epilogue anyway.
+// 128 x 256 output tile, 512 threads = EIGHT waves that all multiply (2 x 4, a 64x64 block each),
+// two per SIMD: while one wave waits for its fragments or at the barrier the other keeps the
+// matrix pipe busy.  B's two plane images come global -> LDS by LDS-DMA (global_load_lds_dwordx4:
+// no registers, no ds_write, no vector ALU), A is split by the multiplying waves themselves
+// between their matrix instructions: 8 elements per thread and k-tile (two 16-byte loads, the
+// split, two ds_write_b128).  Two LDS buffers, one barrier per k-tile, loads and DMAs counted by
+// hand (inline assembly: beside LDS-DMA in flight the compiler drains every load before a
+// ds_write of its own).  tools/gemm_planes_lab.hip measured the form first, on three bf16 planes
+// (200 TF on 51200 x 1024 x 1024 against 177 for four multiplying waves fed by four producer
+// waves); tools/gemm_f16x2_lab.hip the same form on two fp16 planes (320 TF).
 // Work units: output tiles, plus the tail split of the last partial round (packed 128x256 slabs,
 // gemm_wide_tail_reduce_kernel).
 constexpr int WBN = 256;
-constexpr int WIDE_BUF_BYTES = 3 * OPERAND_BYTES;      // A image | two B images
-
-__device__ __forceinline__ void wide_stage_b(const char *b_img, int64_t b_stride, char *buf, int wave, int lane) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  // 48 chunks of 1 KB over 8 waves: 3 per image and wave, lane-linear (the images are byte copies)
-  const unsigned voff = (unsigned)(wave * 3 * 1024 + lane * 16), loff = (unsigned)(wave * 3 * 1024);
-#pragma unroll
-  for (int img = 0; img < 2; ++img)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      __builtin_amdgcn_global_load_lds((const void *)(b_img + (int64_t)img * b_stride + voff + c * 1024),
-                                       (lds_void *)(buf + img * OPERAND_BYTES + loff + c * 1024), 16, 0, 0);
-}
-
-// three bf16 planes of 8 consecutive k of one row into the A image (stores the compiler does not
-// see, see above)
-__device__ __forceinline__ void wide_split_store(const f32x4 &u, const f32x4 &v, char *dst) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  unsigned pl[3][4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const f32x4 &x = h ? v : u;
-    const unsigned p01 = pack_bf16(x[0], x[1]), p23 = pack_bf16(x[2], x[3]);
-    const float e0 = x[0] - __uint_as_float(p01 << 16), e1 = x[1] - __uint_as_float(p01 & 0xffff0000u);
-    const float e2 = x[2] - __uint_as_float(p23 << 16), e3 = x[3] - __uint_as_float(p23 & 0xffff0000u);
-    const unsigned q01 = pack_bf16(e0, e1), q23 = pack_bf16(e2, e3);
-    const float f0 = e0 - __uint_as_float(q01 << 16), f1 = e1 - __uint_as_float(q01 & 0xffff0000u);
-    const float f2 = e2 - __uint_as_float(q23 << 16), f3 = e3 - __uint_as_float(q23 & 0xffff0000u);
-    pl[0][2 * h] = p01; pl[0][2 * h + 1] = p23;
-    pl[1][2 * h] = q01; pl[1][2 * h + 1] = q23;
-    pl[2][2 * h] = pack_bf16(f0, f1); pl[2][2 * h + 1] = pack_bf16(f2, f3);
-  }
-  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dst;
-  static_assert(PLANE_BYTES == 8192, "plane offsets below");
-  const u32x4 w0 = {pl[0][0], pl[0][1], pl[0][2], pl[0][3]};
-  const u32x4 w1 = {pl[1][0], pl[1][1], pl[1][2], pl[1][3]};
-  const u32x4 w2 = {pl[2][0], pl[2][1], pl[2][2], pl[2][3]};
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w0) : "memory");
-  asm volatile("ds_write_b128 %0, %1 offset:8192" ::"v"(addr), "v"(w1) : "memory");
-  asm volatile("ds_write_b128 %0, %1 offset:16384" ::"v"(addr), "v"(w2) : "memory");
-}
-
-template <bool ACT>
-__global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs g) {
-  extern __shared__ __align__(16) char smem[];        // 2 x (A image | 2 B images)
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  constexpr int LA = ACT ? 6 : 2;                      // loads per thread and k-tile: A (+ coefficients)
-
-  // unit -> (tile, k-split); g.tiles_n counts 256-wide column tiles here
-  const int tail_units = g.tail_splits > 1;
-  const int nwg = tail_units ? (int)g.tail_first : (int)g.units;
-  const int u_id = blockIdx.x;
-  const bool tail = tail_units && u_id >= nwg;
-  int tile, sp = 0;
-  int64_t kchunk = g.K;
-  if (tail) {
-    const int v = u_id - nwg;
-    tile = nwg + v / (int)g.tail_splits;
-    sp = v % (int)g.tail_splits;
-    kchunk = g.tail_kchunk;
-  } else {
-    const int q = nwg >> 3, rr = nwg & 7;
-    const int xcd = u_id & 7, idx = u_id >> 3;
-    tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
-  }
-  tile = __builtin_amdgcn_readfirstlane(tile);
-  sp = __builtin_amdgcn_readfirstlane(sp);
-  const int tn = tile % (int)g.tiles_n, tm = tile / (int)g.tiles_n;
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * WBN;
-  const int64_t kbeg = sp * kchunk;
-  const int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
-  const int64_t klen = kend - kbeg;
-  const int ntf = __builtin_amdgcn_readfirstlane((int)(klen / BK));
-  const int rem = __builtin_amdgcn_readfirstlane((int)(klen - (int64_t)ntf * BK));
-  const int nt = ntf + (rem ? 1 : 0);
-  // a partial last tile of at most 16 k holds nothing in its second k-step (K = 1000: 8 of 32)
-  const int nfull = (rem > 0 && rem <= 16) ? nt - 1 : nt;
-
-  // A: the thread owns row t>>2 of the tile, k = 8 (t&3) .. +7 of every k-tile
-  int64_t arow = t >> 2;
-  if (m0 + arow >= g.M) arow = g.M - 1 - m0;           // clamped rows only reach unstored accumulators
-  const int kq = 8 * (t & 3);
-  const unsigned a_off = (unsigned)((arow * g.lda + kq) * 4);
-  const unsigned a_lds = plane_offset(t >> 2, 2 * (t & 3));
-  const char *a_base = reinterpret_cast<const char *>(g.A + m0 * g.lda + kbeg);
-  const char *cs_base = reinterpret_cast<const char *>(g.act_scale + kbeg);
-  const char *ch_base = reinterpret_cast<const char *>(g.act_shift + kbeg);
-  const char *b_img = g.b_planes + ((int64_t)tn * 2 * g.b_ktiles + kbeg / BK) * OPERAND_BYTES;
-  const int64_t bs = g.b_ktiles * (int64_t)OPERAND_BYTES;
-
-  f32x4 u, v, su, sv, hu, hv;
-  // loads of k-tile KT: the same number for a full and for the partial tile (whose k beyond `rem`
-  // read the tile's first k instead and are zeroed once landed)
-  auto load_a = [&](int kt) {
-    const char *tp = a_base + (int64_t)kt * (BK * 4);
-    unsigned ou = a_off, ov = a_off + 16, cu = 4u * kq, cv = 4u * kq + 16;
-    if (kt >= ntf) {
-      if (kq >= rem) { ou = a_off - 4u * kq; cu = 0; }
-      if (kq + 4 >= rem) { ov = a_off - 4u * kq; cv = 0; }
-    }
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(u) : "v"(ou), "s"(tp));
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(ov), "s"(tp));
-    if constexpr (ACT) {
-      const char *sp_ = cs_base + (int64_t)kt * (BK * 4), *hp_ = ch_base + (int64_t)kt * (BK * 4);
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(su) : "v"(cu), "s"(sp_));
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sv) : "v"(cv), "s"(sp_));
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hu) : "v"(cu), "s"(hp_));
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hv) : "v"(cv), "s"(hp_));
-    }
-  };
-  // landed tile KT: prologue, zero fill of a partial tile, split, planes into buffer KT & 1
-  auto split_a = [&](int kt) {
-    if constexpr (ACT) asm volatile("" : "+v"(u), "+v"(v), "+v"(su), "+v"(sv), "+v"(hu), "+v"(hv));
-    else asm volatile("" : "+v"(u), "+v"(v));
-    if constexpr (ACT) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = u[j] * su[j] + hu[j], b = v[j] * sv[j] + hv[j];
-        u[j] = fmaxf(a, a * g.act_slope);
-        v[j] = fmaxf(b, b * g.act_slope);
-      }
-    }
-    if (kt >= ntf) {                                   // (K need not be a multiple of 4, see run_gemm)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (kq + j >= rem) u[j] = 0.f;
-        if (kq + 4 + j >= rem) v[j] = 0.f;
-      }
-    }
-    wide_split_store(u, v, smem + (kt & 1) * WIDE_BUF_BYTES + a_lds);
-  };
-
-  f32x16 hi[2][2], lo[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
-
-  wide_stage_b(b_img, bs, smem + OPERAND_BYTES, wave, lane);
-  load_a(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  split_a(0);
-  if (nt > 1) load_a(1);
-
-  for (int it = 0; it < nfull; ++it) {
-    const bool more = it + 1 < nt;
-    // B(it) has landed (the loads of A(it+1) may still fly); this wave's plane stores are done
-    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // ... of every wave; the other buffer is free
-    asm volatile("" ::: "memory");
-    if (more)
-      wide_stage_b(b_img + (int64_t)(it + 1) * OPERAND_BYTES, bs,
-                   smem + ((it + 1) & 1) * WIDE_BUF_BYTES + OPERAND_BYTES, wave, lane);
-    const char *As = smem + (it & 1) * WIDE_BUF_BYTES;
-    const char *Bs = As + OPERAND_BYTES + (wn >> 1) * OPERAND_BYTES;
-    const int bn0 = (wn & 1) * 64;
-    bf16x8 P[3], Q[3], R[3], S[3];
-    read_set(As, wm * 64, lane, 0, P);
-    read_set(Bs, bn0, lane, 0, Q);
-    read_set(Bs, bn0 + 32, lane, 0, R);
-    read_set(As, wm * 64 + 32, lane, 0, S);
-    __builtin_amdgcn_sched_barrier(0);
-    // the first half of a k-tile's matrix instructions runs at raised priority, the split and the
-    // second half at normal priority: the two waves of a SIMD then fall half a k-tile out of
-    // step and fill each other's gaps (+4 % on the layer products; raising both halves, or
-    // only the first two groups, loses it again)
-    __builtin_amdgcn_s_setprio(1);
-    mma6(P, Q, hi[0][0], lo[0][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(P, R, hi[0][1], lo[0][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set(As, wm * 64, lane, 1, P);
-    mma6(S, R, hi[1][1], lo[1][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set(Bs, bn0 + 32, lane, 1, R);
-    mma6(S, Q, hi[1][0], lo[1][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set(Bs, bn0, lane, 1, Q);
-    read_set(As, wm * 64 + 32, lane, 1, S);
-    __builtin_amdgcn_s_setprio(0);
-    if (more) {
-      // A(it+1) landed long ago (only this iteration's six DMAs are younger): split it into the
-      // other buffer, then its registers take the loads of A(it+2)
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      split_a(it + 1);
-      if (it + 2 < nt) load_a(it + 2);
-    }
-    mma6(P, R, hi[0][1], lo[0][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(P, Q, hi[0][0], lo[0][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(S, Q, hi[1][0], lo[1][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(S, R, hi[1][1], lo[1][1]);
-  }
-  if (nfull < nt) {                                    // the short last tile: first k-step only
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const char *As = smem + (nfull & 1) * WIDE_BUF_BYTES;
-    const char *Bs = As + OPERAND_BYTES + (wn >> 1) * OPERAND_BYTES;
-    const int bn0 = (wn & 1) * 64;
-    bf16x8 P[3], Q[3], R[3], S[3];
-    read_set(As, wm * 64, lane, 0, P);
-    read_set(Bs, bn0, lane, 0, Q);
-    read_set(Bs, bn0 + 32, lane, 0, R);
-    read_set(As, wm * 64 + 32, lane, 0, S);
-    mma6(P, Q, hi[0][0], lo[0][0]);
-    mma6(P, R, hi[0][1], lo[0][1]);
-    mma6(S, R, hi[1][1], lo[1][1]);
-    mma6(S, Q, hi[1][0], lo[1][0]);
-  }
-
-  // epilogue, straight from the accumulators.  C/D layout of the 32x32 MFMA: col = lane & 31,
-  // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-  const int kh = lane >> 5, xl = lane & 31;
-  if (tail) {
-    float *slab = g.tail_slabs + ((int64_t)(tile - nwg) * g.tail_splits + sp) * (BM * WBN);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          slab[(wm * 64 + i * 32 + 4 * kh + (r & 3) + 8 * (r >> 2)) * WBN + wn * 64 + j * 32 + xl] =
-              hi[i][j][r] + lo[i][j][r];
-    return;
-  }
-  // (the bias values are waited for ONCE, here: a compiler-counted load would be waited for with
-  // vmcnt(0) before every store that uses it, which also waits for the store before it)
-  const int64_t col0 = n0 + wn * 64 + xl;
-  float bv0 = (g.bias && col0 < g.N) ? g.bias[col0] : 0.f;
-  float bv1 = (g.bias && col0 + 32 < g.N) ? g.bias[col0 + 32] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv0), "+v"(bv1)::"memory");
-  if (g.c_vec && m0 + BM <= g.M) {
-    // all 128 rows exist and rows can be written 16 bytes per lane: the wave transposes its
-    // block, 32 rows at a time, through 8 KB of the LDS buffer that the last k-tile did not use
-    // (free since the barrier before it; the region is this wave's alone and a wave's LDS
-    // accesses execute in order) and stores 256-byte row segments, non-temporal.  Dword stores
-    // from the accumulator layout wrote 128-byte segments at 4016-byte row strides: 40 % more
-    // bytes at the memory than the tile holds.
-    float *ws = reinterpret_cast<float *>(smem + (nt & 1) * WIDE_BUF_BYTES) + wave * (32 * 64);
-    const int c = (lane & 15) * 4;
-    const int64_t col = n0 + wn * 64 + c;
-    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && col < g.N) bq = *reinterpret_cast<const f32x4 *>(g.bias + col);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq)::"memory");
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ws[(4 * kh + (r & 3) + 8 * (r >> 2)) * 64 + ((j * 32 + xl) ^ (kh << 5))] = hi[i][j][r] + lo[i][j][r];
-      if (col < g.N) {                               // N % 4 == 0: the four columns exist together
-        float *orow = g.C + (m0 + wm * 64 + i * 32 + (lane >> 4)) * g.ldc + col;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const f32x4 x = *reinterpret_cast<const f32x4 *>(&ws[(q * 4 + (lane >> 4)) * 64 + (c ^ ((q & 1) << 5))]);
-          __builtin_nontemporal_store(x + bq, reinterpret_cast<f32x4 *>(orow + (int64_t)q * 4 * g.ldc));
-        }
-      }
-    }
-    return;
-  }
-  float *o = g.C + (m0 + wm * 64 + 4 * kh) * g.ldc + col0;
-  if (m0 + BM <= g.M) {
-    // all 128 rows exist: stores are only predicated on the column of the lane
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (col0 + j * 32 < g.N) {
-        const float bv = j ? bv1 : bv0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            o[(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32] = hi[i][j][r] + lo[i][j][r] + bv;
-      }
-    }
-    return;
-  }
-  const int64_t rbase = m0 + wm * 64 + 4 * kh;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const bool colok = col0 + j * 32 < g.N;
-    const float bv = j ? bv1 : bv0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-        if (colok && rbase + rr < g.M) o[rr * g.ldc + j * 32] = hi[i][j][r] + lo[i][j][r] + bv;
-      }
-  }
-}
-
 // second stage of the wide form's tail split: C tile = sum_s slab[tile][s] + bias in split order.
 // One workgroup per 16 rows of a tail tile; a thread owns 4 consecutive columns of 4 rows.
 __global__ __launch_bounds__(256) void gemm_wide_tail_reduce_kernel(GemmArgs g) {
@@ -1107,229 +811,31 @@ __global__ __launch_bounds__(256) void gemm_wide_tail_reduce_kernel(GemmArgs g) 
 // layer's output gradient) and B = [K][N] (its input, optionally behind the deferred
 // BatchNorm + LeakyReLU prologue), K = graph nodes of the batch, M and N = layer widths.
 //
-// Same shape as gemm_wide_kernel (128 x 256 tile, eight multiplying waves, two 72 KB buffers, one
-// barrier per k-tile), but a thread that loads 16 bytes of such an operand holds ONE k of four x
-// where a matrix-instruction operand wants eight k of one x.  The planes therefore stay k-major
-// in LDS ([k][x] bf16 rows of 256 bytes, the 16-byte chunk index XOR-ed with the row: the
-// dual-use image of the MI355X guide), a thread stores its four bf16 of a plane with one
-// ds_write_b64, and the fragments come out through the transposing read of gfx950
+// (gemm_kmajor_wide_h_kernel, further down.)  Same shape as the wide form (128 x 256 tile, eight
+// multiplying waves, two LDS buffers, one barrier per k-tile), but a thread that loads 16 bytes of
+// such an operand holds ONE k of four x where a matrix-instruction operand wants eight k of one
+// x.  The planes therefore stay k-major in LDS ([k][x] rows of 256 bytes of 16-bit elements, the
+// 16-byte chunk index XOR-ed with the row: the dual-use image of the MI355X guide), a thread
+// stores its four elements of a plane with one ds_write_b64, and the fragments come out through
+// the transposing read of gfx950
 // (ds_read_b64_tr_b16: a 4-row x 16-column block per 16 lanes, delivered column-major; two of
 // them make the eight k of a lane).  Per thread and k-tile: six 16-byte loads (two of A, four of
 // B) where the producer / consumer kernel needs 32 4-byte loads per producer thread; each float4
 // is split after one of the six first blocks of matrix instructions of the tile before, so that
-// its ~26 vector instructions issue between the dependent matrix instructions of the block, and
+// its vector instructions issue between the dependent matrix instructions of the block, and
 // its registers take the load of the tile after next at once (one register set, the count of
 // loads in flight is the same at every wait: 5 younger ones).
-// tools/gemm_kmajor_lab.hip measured the form first: 196 TF on 1024 x 1024 x 51200 in 256 units
-// against 163-167 for the producer / consumer kernel on the same product.
+// tools/gemm_kmajor_lab.hip measured the form first, on three bf16 planes: 196 TF on
+// 1024 x 1024 x 51200 in 256 units against 163-167 for the producer / consumer kernel.
 // Work units: (tile, k-split) pairs, one round of the chip, k-split fastest so that the units of
 // one k-range (which share its rows of A and B) run on one XCD; packed 128 x 256 slabs, summed in
-// split order by gemm_wide_tail_reduce_kernel.  M % 4 == N % 4 == 0 (a float4 of an operand row is
-// inside or outside as a whole; outside ones read column 0 of the tile and only reach unstored
-// accumulators).  The rows of a partial last k-tile are multiplied after the pipelined loop, in
+// split order by gemm_wide_tail_reduce_kernel.  M % 4 == 0, and N % 4 == 0 or rows of B padded
+// to a multiple of 4 (a float4 of an operand row is inside or outside as a whole, or straddles N
+// over readable padding; outside ones read column 0 of the tile; either way the extra columns
+// only reach unstored accumulators).  The rows of a partial last k-tile are multiplied after the pipelined loop, in
 // a step of their own whose loads are clamped to row K - 1 and whose A elements beyond K are zero.
 __device__ __forceinline__ unsigned kmajor_offset(int k, int ch) {   // 16-byte chunk ch of row k
   return (unsigned)(256 * k + 16 * (ch ^ (((k & 3) << 2) | ((k >> 2) & 3))));
-}
-
-// four x of one k -> 8 bytes in each of the three planes of a k-major image
-__device__ __forceinline__ void kmajor_split_store(const f32x4 &x, char *dst) {
-  const unsigned p01 = pack_bf16(x[0], x[1]), p23 = pack_bf16(x[2], x[3]);
-  const float e0 = x[0] - __uint_as_float(p01 << 16), e1 = x[1] - __uint_as_float(p01 & 0xffff0000u);
-  const float e2 = x[2] - __uint_as_float(p23 << 16), e3 = x[3] - __uint_as_float(p23 & 0xffff0000u);
-  const unsigned q01 = pack_bf16(e0, e1), q23 = pack_bf16(e2, e3);
-  const float f0 = e0 - __uint_as_float(q01 << 16), f1 = e1 - __uint_as_float(q01 & 0xffff0000u);
-  const float f2 = e2 - __uint_as_float(q23 << 16), f3 = e3 - __uint_as_float(q23 & 0xffff0000u);
-  *reinterpret_cast<uint2 *>(dst) = make_uint2(p01, p23);
-  *reinterpret_cast<uint2 *>(dst + PLANE_BYTES) = make_uint2(q01, q23);
-  *reinterpret_cast<uint2 *>(dst + 2 * PLANE_BYTES) = make_uint2(pack_bf16(f0, f1), pack_bf16(f2, f3));
-}
-
-// the three planes of a 32-x sub-tile for one 16-deep k-step, transposed on the way out of LDS:
-// lane l gets x = xbase + (l & 31), k = 16 step + 8 (l >> 5) .. +7
-__device__ __forceinline__ void read_set_tr(const char *img, int xbase, int lane, int step, bf16x8 (&f)[3]) {
-  typedef short s16x4 __attribute__((ext_vector_type(4)));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const int gq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  const int ch = ((xbase + 16 * (gq & 1)) >> 3) + (p >> 1);
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    s16x4 h[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int row = 16 * step + 8 * (gq >> 1) + 4 * hh + q;
-      const char *a = img + pl * PLANE_BYTES + kmajor_offset(row, ch) + 8 * (p & 1);
-      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)a);
-    }
-    const s16x8 v = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
-    f[pl] = __builtin_bit_cast(bf16x8, v);
-  }
-}
-
-template <bool ACT>
-__global__ __launch_bounds__(512) void gemm_kmajor_wide_kernel(GemmArgs g) {
-  extern __shared__ __align__(16) char smem[];        // 2 x (A image | 2 B images), k-major
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nsp = (int)g.tail_splits;
-  const int sp = __builtin_amdgcn_readfirstlane((int)blockIdx.x % nsp);
-  const int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x / nsp);
-  const int tn = tile % (int)g.tiles_n, tm = tile / (int)g.tiles_n;
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * WBN;
-  const int64_t kbeg = sp * g.tail_kchunk;
-  const int64_t kend = (kbeg + g.tail_kchunk < g.K) ? (kbeg + g.tail_kchunk) : g.K;
-  const int ntf = __builtin_amdgcn_readfirstlane((int)((kend - kbeg) / BK));
-  const int rem = __builtin_amdgcn_readfirstlane((int)(kend - kbeg - (int64_t)ntf * BK));
-
-  // A: the thread owns x = 4 (t & 31) .. +3 of rows k = t >> 5 and 16 + (t >> 5) of every k-tile
-  // B: x = 4 (t & 63) .. +3 of rows k = (t >> 6) + 8 j, j = 0..3
-  const int ax = 4 * (t & 31), ak = t >> 5;
-  const int bx = 4 * (t & 63), bk = t >> 6;
-  const int axc = (m0 + ax < g.M) ? ax : 0, bxc = (n0 + bx < g.N) ? bx : 0;
-  const char *a_base = reinterpret_cast<const char *>(g.A + kbeg * g.lda + m0);
-  const char *b_base = reinterpret_cast<const char *>(g.B + kbeg * g.ldb + n0);
-  auto krow = [&](int j) { return j < 2 ? ak + 16 * j : bk + 8 * (j - 2); };
-  unsigned off[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j)
-    off[j] = j < 2 ? (unsigned)((krow(j) * g.lda + axc) * 4) : (unsigned)((krow(j) * g.ldb + bxc) * 4);
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (ACT) {
-    sc = *reinterpret_cast<const f32x4 *>(g.act_scale + n0 + bxc);
-    sh = *reinterpret_cast<const f32x4 *>(g.act_shift + n0 + bxc);
-  }
-  f32x4 r[6];
-  auto tile_a = [&](int kt) { return a_base + (int64_t)kt * BK * g.lda * 4; };
-  auto tile_b = [&](int kt) { return b_base + (int64_t)kt * BK * g.ldb * 4; };
-  // piece j of a landed tile: prologue (B), split, planes into buffer `buf`
-  auto split_piece = [&](int j, char *buf) {
-    if (j < 2) {
-      kmajor_split_store(r[j], buf + kmajor_offset(krow(j), ax >> 3) + 2 * (ax & 7));
-    } else {
-      f32x4 v = r[j];
-      if constexpr (ACT) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = v[e] * sc[e] + sh[e];
-          v[e] = fmaxf(a, a * g.act_slope);
-        }
-      }
-      kmajor_split_store(v, buf + OPERAND_BYTES + (bx >> 7) * OPERAND_BYTES +
-                                kmajor_offset(krow(j), (bx & 127) >> 3) + 2 * (bx & 7));
-    }
-  };
-
-  f32x16 hi[2][2], lo[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { hi[i][j][q] = 0.f; lo[i][j][q] = 0.f; }
-
-  // one k-tile out of buffer `As`; piece(j) runs after the j-th block of matrix instructions
-  auto multiply = [&](const char *As, auto &&piece) {
-    const char *Bs = As + OPERAND_BYTES + (wn >> 1) * OPERAND_BYTES;
-    const int bn0 = (wn & 1) * 64;
-    bf16x8 P[3], Q[3], R[3], S[3];
-    read_set_tr(As, wm * 64, lane, 0, P);
-    read_set_tr(Bs, bn0, lane, 0, Q);
-    read_set_tr(Bs, bn0 + 32, lane, 0, R);
-    read_set_tr(As, wm * 64 + 32, lane, 0, S);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mma6(P, Q, hi[0][0], lo[0][0]);
-    piece(0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(P, R, hi[0][1], lo[0][1]);
-    piece(1);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set_tr(As, wm * 64, lane, 1, P);
-    mma6(S, R, hi[1][1], lo[1][1]);
-    piece(2);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set_tr(Bs, bn0 + 32, lane, 1, R);
-    mma6(S, Q, hi[1][0], lo[1][0]);
-    piece(3);
-    __builtin_amdgcn_sched_barrier(0);
-    read_set_tr(Bs, bn0, lane, 1, Q);
-    read_set_tr(As, wm * 64 + 32, lane, 1, S);
-    __builtin_amdgcn_s_setprio(0);
-    mma6(P, R, hi[0][1], lo[0][1]);
-    piece(4);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(P, Q, hi[0][0], lo[0][0]);
-    piece(5);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(S, Q, hi[1][0], lo[1][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma6(S, R, hi[1][1], lo[1][1]);
-  };
-  auto nothing = [](int) {};
-
-  if (ntf > 0) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? tile_a(0) : tile_b(0)));
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5])::"memory");
-#pragma unroll
-    for (int j = 0; j < 6; ++j) split_piece(j, smem);
-    const int t1 = ntf > 1 ? 1 : 0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? tile_a(t1) : tile_b(t1)));
-    for (int it = 0; it + 1 < ntf; ++it) {
-      __syncthreads();                                 // the planes of tile it are in buffer it & 1
-      char *other = smem + ((it + 1) & 1) * WIDE_BUF_BYTES;
-      const int kt = it + 2 < ntf ? it + 2 : ntf - 1;  // (the last reload is a repeat, never used)
-      const char *ta = tile_a(kt), *tb = tile_b(kt);
-      multiply(smem + (it & 1) * WIDE_BUF_BYTES, [&](int j) {
-        asm volatile("s_waitcnt vmcnt(5)" : "+v"(r[j]));
-        split_piece(j, other);
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(off[j]), "s"(j < 2 ? ta : tb));
-      });
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  if (rem > 0) {
-    // the partial k-tile: loads in flight across the last full tile's matrix instructions
-    const char *ta = tile_a(ntf), *tb = tile_b(ntf);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int kr = krow(j) < rem ? krow(j) : rem - 1;
-      const unsigned o = j < 2 ? (unsigned)((kr * g.lda + axc) * 4) : (unsigned)((kr * g.ldb + bxc) * 4);
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r[j]) : "v"(o), "s"(j < 2 ? ta : tb));
-    }
-  }
-  if (ntf > 0) {
-    __syncthreads();
-    multiply(smem + ((ntf - 1) & 1) * WIDE_BUF_BYTES, nothing);
-  }
-  if (rem > 0) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5])::"memory");
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (krow(j) >= rem) r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    char *buf = smem + (ntf & 1) * WIDE_BUF_BYTES;    // last read two barriers ago
-#pragma unroll
-    for (int j = 0; j < 6; ++j) split_piece(j, buf);
-    __syncthreads();
-    multiply(buf, nothing);
-  }
-
-  // packed slab of the unit, straight from the accumulators: 128-byte segments of 1 KB rows
-  const int kh = lane >> 5, xl = lane & 31;
-  float *slab = g.tail_slabs + ((int64_t)tile * nsp + sp) * (BM * WBN);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
-        slab[(wm * 64 + i * 32 + 4 * kh + (q & 3) + 8 * (q >> 2)) * WBN + wn * 64 + j * 32 + xl] =
-            hi[i][j][q] + lo[i][j][q];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2286,7 +1792,12 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   }
   // the wide form for k-major operands (weight gradients): both operands readable 16 bytes at a
   // time along x, plain epilogue (bias at most), B prologue allowed
-  if (plan.km_splits > 1 && trans_a && !trans_b && g.a_vec && g.b_vec && !presplit && !row_scale &&
+  // (an N that is not a multiple of 4 is taken when the rows of B are padded to one and there is
+  // no prologue on it: the float4 that straddles N is readable and only reaches accumulators that
+  // are not stored - the class-count gradient of the logits layer, 1001 columns in rows of 1004)
+  const bool b_cols16 = g.b_vec || (!trans_b && act_operand == 0 && ldb % 4 == 0 &&
+                                    (((uintptr_t)b & 15) == 0) && ldb >= ((n + 3) & ~3ll));
+  if (plan.km_splits > 1 && trans_a && !trans_b && g.a_vec && b_cols16 && !presplit && !row_scale &&
       !accumulate && act_operand != 1) {
     TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gemm_f32: workspace must be 16-byte aligned");
     GemmArgs w = g;
