@@ -300,6 +300,53 @@ int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
                          void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * One GATConvAgg layer of a TRAINING step as one call each way (model/gnn_layers.py:112-157:
+ * GATConv, head concat; the BatchNorm + LeakyReLU that FOLLOWS the previous layer rides in this
+ * layer's products).  The two calls issue exactly the launches of the operator-level entry
+ * points above, in the same order with the same arguments (bit-equal results); they exist for
+ * hosts whose cost per crossing of this boundary is of the order of a kernel's run time (a
+ * Python host at the reference's batch size of 64 traces).
+ * Forward: [tv_bn_finalize_coeffs of the input's statistics] -> tv_gat_fc_score_weight ->
+ *   tv_gemm_f32_ex (A prologue when the input is deferred) -> tv_gat_aggregate_fwd.
+ *   in_coeffs == NULL: x is a plain input; else [4, pad4(in_feats)] floats that receive mean,
+ *   rstd, scale, shift of the input's BatchNorm (in_stats [in_nblk, 2, in_feats], in_count rows).
+ *   weight_ext [H*F + pad4(2H), in_feats], ft [rows, H*F + pad4(2H)], out [rows, H*F],
+ *   alpha [E, H], out_stats [tv_stat_blocks(rows), 2, H*F] (NULL: none) are written;
+ *   x_max / w_max: TV_GEMM_MAX_SLOTS floats each, as in tv_gemm_f32_ex (x_max_state for a plain
+ *   input: 1 or 2; behind a BatchNorm the finalize writes the bound).
+ * Backward: tv_gat_aggregate_bwd (score-gradient columns) -> weight gradient product ->
+ *   tv_gat_fc_score_weight_bwd -> input gradient product -> [tv_bn_lrelu_bwd].
+ *   dweight_ext [H*F + pad4(2H), in_feats]: rows 0..H*F-1 are dW on return.  dx [rows, in_feats];
+ *   dgamma / dbeta [in_feats] with a deferred input.  need_dx / need_dw: skip the products whose
+ *   results nobody reads.  Workspace: tv_gat_layer_workspace_bytes(...) bytes, 256-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+int64_t tv_gat_layer_workspace_bytes(int64_t rows, int64_t in_feats, int64_t heads,
+                                     int64_t feats, int64_t num_edges);
+int tv_gat_layer_train_fwd(int64_t rows, int64_t in_feats, int64_t heads, int64_t feats,
+                           const int64_t *indptr, const int64_t *indices, const float *x,
+                           int64_t x_stride, const float *in_stats, int64_t in_nblk,
+                           int64_t in_count, float eps, float momentum, float slope,
+                           const float *in_gamma, const float *in_beta, float *in_running_mean,
+                           float *in_running_var, float *in_coeffs, const float *weight,
+                           const float *attn_l, const float *attn_r, const float *bias,
+                           const float *stats_row_weight, float *weight_ext, float *ft,
+                           float *out, float *alpha, float *out_stats, float *x_max,
+                           int x_max_state, float *w_max, void *workspace,
+                           int64_t workspace_bytes, void *stream);
+int tv_gat_layer_train_bwd(int64_t rows, int64_t in_feats, int64_t heads, int64_t feats,
+                           int64_t num_edges, const int64_t *indptr, const int64_t *indices,
+                           const int64_t *rev, const float *x, int64_t x_stride,
+                           const float *in_coeffs, const float *in_gamma, const float *in_beta,
+                           float slope, const float *in_row_weight, int64_t in_count,
+                           const float *weight, const float *attn_l, const float *attn_r,
+                           const float *weight_ext, const float *ft, const float *alpha,
+                           const float *dout, float *x_max, int x_max_state, float *w_max,
+                           int w_max_state, int need_dx, int need_dw, float *dweight_ext,
+                           float *dattn_l, float *dattn_r, float *dbias, float *dx,
+                           float *dgamma, float *dbeta, void *workspace,
+                           int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * BatchNorm over rows + LeakyReLU (tk.layers.BatchNorm = torch BatchNorm1d, then
  * tk.layers.LeakyReLU; model/gnn_layers.py:152-155 and every `dense` of the MLPs,
  * model/struct_vae.py:117-120).

@@ -543,3 +543,39 @@ def test_deferred_batch_norm_equals_materialised(device, monkeypatch):
     for n, want in b['grads'].items():
         scale = max(float(want.abs().max()), 1e-4 * gmax)
         assert float((a['grads'][n] - want).abs().max()) / scale < 1e-3, n
+
+
+@pytest.mark.parametrize('latency_only', [False, True])
+def test_fused_gat_layer_calls_are_bit_equal_to_the_operator_level_path(device, monkeypatch,
+                                                                       latency_only):
+    """`tv_gat_layer_train_fwd / _bwd` (one library call per GAT layer and direction) issue the
+    launches of the operator-level entry points: a whole training step - loss, every gradient in
+    the flat bucket, BatchNorm buffers, updated parameters - is bit for bit the same either way,
+    in phase 1 and in phase 2 (frozen struct model: some layers need no weight gradient, the
+    first layers no input gradient)."""
+    import tracevae_amd.model as model
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.train import Trainer
+    V, M = 60, 16
+    results = {}
+    for fused in (True, False):
+        monkeypatch.setattr(model, 'FUSED_GAT_LAYER', fused)
+        cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 3, 12, seed=23)
+        B = len(flat)
+        g = torch.Generator().manual_seed(3)
+        eps = {'z': torch.randn(B, 10, generator=g), 'z2': torch.randn(B, 10, generator=g)}
+        trainer = Trainer(vae, cfg, latency_only=latency_only, world_size=1)
+        G = TraceGraphBatch.from_store(store, np.arange(B), M)
+        out = trainer.local_gradients(G, eps)
+        grad = trainer.flat.grad.clone()
+        trainer.update()
+        results[fused] = dict(loss=out['loss'].detach().clone(), grad=grad,
+                              flat=trainer.flat.flat.clone(),
+                              stats={k: v.clone() for k, v in vae.state_dict().items()
+                                     if 'running_' in k or 'num_batches' in k})
+    a, b = results[True], results[False]
+    assert torch.equal(a['loss'], b['loss'])
+    assert torch.equal(a['grad'], b['grad']) and float(a['grad'].abs().max()) > 0
+    assert torch.equal(a['flat'], b['flat'])
+    for k in b['stats']:
+        assert torch.equal(a['stats'][k], b['stats'][k]), k

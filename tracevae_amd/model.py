@@ -46,6 +46,11 @@ LRELU_SLOPE = 0.01
 # instead of as a pass of its own (the materialised form serves the layers in front of a pooling
 # or GraphConv tail and eval mode; the equivalence test patches this constant)
 FUSED_BN_LINEAR = True
+# training: a GAT layer as one library call each way (`ops.gat_layer_train`) instead of one call
+# per kernel - the same launches, issued from inside the library (the equivalence test patches
+# this constant; a kernel-timing run, `ops.TIMER.enabled`, takes the operator-level calls, whose
+# HIP events bracket single kernels)
+FUSED_GAT_LAYER = True
 
 
 # ---------------------------------------------------------------------------------------
@@ -242,12 +247,27 @@ class GATConvAgg(nn.Module):
         (compact latency decoder); only the BatchNorm statistics see the difference.
         `defer`: in training mode return a `_DeferredBN` for the next GAT layer to consume."""
         g = self.gnn
+        bn = self.normalization
+        if bn is not None and bn.training and n_rep == 1 and FUSED_GAT_LAYER and FUSED_BN_LINEAR \
+                and not ops.TIMER.enabled:
+            deferred = None
+            x = h
+            if isinstance(h, _DeferredBN):
+                b = h.bn
+                b.count_batch()
+                deferred = ops.DeferredInput(h.stats, b.weight, b.bias, b.running_mean, b.running_var,
+                                             b.eps, b.momentum, h.row_weight, h.count)
+                x = h.x
+            out, stats = ops.gat_layer_train(x, g.fc.weight, g.attn_l, g.attn_r, g.bias, graph,
+                                             deferred, LRELU_SLOPE, row_weight)
+            if defer:
+                return _DeferredBN(out, stats, bn, row_weight, count)
+            return bn.forward_lrelu(out, stats, row_weight, count)
         # [ft | el | er]: the attention scores are 2H more columns of the fc product
         if isinstance(h, _DeferredBN):
             ft = h.linear(g.fc.weight, g.attn_l, g.attn_r)
         else:
             ft = ops.linear_scores(h, g.fc.weight, g.attn_l, g.attn_r)
-        bn = self.normalization
         if bn is None:
             out, _ = ops.gat_conv(ft, g.attn_l, g.attn_r, g.bias, graph, n_rep)
             return _Identity.lrelu(out)

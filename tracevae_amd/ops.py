@@ -14,7 +14,7 @@ from . import hip
 
 __all__ = [
     'DeviceGraph', 'TIMER', 'gemm', 'linear', 'matmul_nn', 'rowdot', 'colsum', 'gat_conv', 'bn_lrelu', 'bn_lrelu_linear',
-    'graph_sum', 'segment_mean', 'embedding', 'latdec_input', 'latdec_rows', 'adj_bernoulli_ll',
+    'gat_layer_train', 'DeferredInput', 'graph_sum', 'segment_mean', 'embedding', 'latdec_input', 'latdec_rows', 'adj_bernoulli_ll',
     'categorical_ll', 'normal_reparam', 'normal_ll', 'realnvp_log_prob', 'realnvp_supported',
     'realnvp_actnorm_init',
     'latency_ll', 'score_reduce',
@@ -585,6 +585,134 @@ def gat_conv(ft, attn_l, attn_r, bias, graph: DeviceGraph, n_rep: int = 1,
 
 
 _LAST_OUT_MAX = {}
+
+
+class DeferredInput(object):
+    """The BatchNorm(batch statistics) + LeakyReLU that a layer's input still has to go through
+    (`gat_layer_train`): statistics partials of x, the BatchNorm's parameters and buffers."""
+    __slots__ = ['stats', 'gamma', 'beta', 'running_mean', 'running_var', 'eps', 'momentum',
+                 'row_weight', 'count']
+
+    def __init__(self, stats, gamma, beta, running_mean, running_var, eps, momentum, row_weight,
+                 count):
+        self.stats, self.gamma, self.beta = stats, gamma, beta
+        self.running_mean, self.running_var = running_mean, running_var
+        self.eps, self.momentum, self.row_weight, self.count = eps, momentum, row_weight, count
+
+
+class _GATLayerTrain(Function):
+    """One GATConvAgg layer of a training step as ONE library call each way
+    (`tv_gat_layer_train_fwd / _bwd`): the launches of `_BNLReLULinear` (or `_LinearScores`) and
+    `_GATConv` with column statistics, issued from inside the library instead of one by one from
+    here.  Same kernels, same order, same arguments: bit-equal to the operator-level path; what it
+    saves is the host's time per launch, which is the bound of a step at small batches."""
+
+    @staticmethod
+    def forward(ctx, x, in_gamma, in_beta, weight, attn_l, attn_r, bias, graph, deferred, slope,
+                stats_row_weight):
+        x_in = x
+        x = _check(x, 'x')
+        weight, bias = _check(weight, 'weight'), _check(bias, 'bias')
+        heads, feats = int(attn_l.shape[-2]), int(attn_l.shape[-1])
+        al, ar = _check(attn_l, 'attn_l').reshape(-1), _check(attn_r, 'attn_r').reshape(-1)
+        rows, k = x.shape
+        hf = heads * feats
+        width = hf + score_columns(heads)
+        dev = x.device
+        if rows != graph.num_rows or tuple(weight.shape) != (hf, k):
+            raise ValueError(f'gat_layer_train: x {tuple(x.shape)} / weight {tuple(weight.shape)} do '
+                             f'not match graph rows {graph.num_rows}, heads {heads} x feats {feats}')
+        count = 0
+        coeffs = None
+        if deferred is not None:
+            count = rows if deferred.row_weight is None else int(deferred.count)
+            if count < 2:
+                raise ValueError('Expected more than 1 value per channel when training')
+            coeffs = torch.empty([4, (k + 3) // 4 * 4], dtype=_f32, device=dev)
+            in_gamma, in_beta = _check(in_gamma, 'gamma'), _check(in_beta, 'beta')
+        wx = torch.empty([width, k], dtype=_f32, device=dev)
+        ft = torch.empty([rows, width], dtype=_f32, device=dev)
+        out = torch.empty([rows, hf], dtype=_f32, device=dev)
+        alpha = torch.empty([graph.num_edges, heads], dtype=_f32, device=dev)
+        stats = torch.empty([hip.query('tv_stat_blocks', rows), 2, hf], dtype=_f32, device=dev)
+        x_max = (operand_max(x_in) if (x is x_in and deferred is None) else None) or OperandMax(dev)
+        w_max = OperandMax(dev)
+        wsb = hip.query('tv_gat_layer_workspace_bytes', rows, k, heads, feats, graph.num_edges)
+        ws = _workspace(wsb, dev)
+        d = deferred
+        hip.call('tv_gat_layer_train_fwd', rows, k, heads, feats, hip.ptr(graph.indptr),
+                 hip.ptr(graph.indices), hip.ptr(x), x.stride(0),
+                 hip.ptr(d.stats) if d else None, d.stats.shape[0] if d else 0, count,
+                 float(d.eps) if d else 0.0, float(d.momentum) if d else 0.0, float(slope),
+                 hip.ptr(in_gamma) if d else None, hip.ptr(in_beta) if d else None,
+                 hip.ptr(d.running_mean) if d else None, hip.ptr(d.running_var) if d else None,
+                 hip.ptr(coeffs), hip.ptr(weight), hip.ptr(al), hip.ptr(ar), hip.ptr(bias),
+                 hip.ptr(stats_row_weight), hip.ptr(wx), hip.ptr(ft), hip.ptr(out), hip.ptr(alpha),
+                 hip.ptr(stats), x_max.slots.data_ptr(), 2 if x_max.valid else 1,
+                 w_max.slots.data_ptr(), hip.ptr(ws), wsb)
+        form = int(hip.lib().tv_gemm_f32_last_form())
+        x_max.valid = x_max.valid or form != 0 or (d is not None and k <= 2048)
+        w_max.valid = form != 0
+        ctx.save_for_backward(x, wx, ft, alpha, weight, al, ar,
+                              *((coeffs, in_gamma, in_beta) if d else ()))
+        ctx.graph, ctx.dims = graph, (rows, k, heads, feats)
+        ctx.deferred = d is not None
+        ctx.row_weight = d.row_weight if d else None
+        ctx.count, ctx.slope = count, float(slope)
+        ctx.x_max, ctx.w_max = x_max, w_max
+        ctx.attn_shape = attn_l.shape
+        ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
+        return out, stats
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout, _dstats):
+        if dout is None:
+            return (None,) * 11
+        x, wx, ft, alpha, weight, al, ar = ctx.saved_tensors[:7]
+        coeffs = in_gamma = in_beta = None
+        if ctx.deferred:
+            coeffs, in_gamma, in_beta = ctx.saved_tensors[7:]
+        rows, k, heads, feats = ctx.dims
+        g = ctx.graph
+        hf = heads * feats
+        width = hf + score_columns(heads)
+        dev = x.device
+        dout = _check(dout, 'dout')
+        need_dx = any(ctx.needs_input_grad[:3])
+        need_dw = any(ctx.needs_input_grad[3:6])
+        dwx = torch.empty([width, k], dtype=_f32, device=dev) if need_dw else None
+        dal = torch.empty([hf], dtype=_f32, device=dev) if need_dw else None
+        dar = torch.empty([hf], dtype=_f32, device=dev) if need_dw else None
+        dbias = torch.empty([hf], dtype=_f32, device=dev)
+        dx = torch.empty_like(x) if need_dx else None
+        dgamma = torch.empty_like(in_gamma) if (ctx.deferred and need_dx) else None
+        dbeta = torch.empty_like(in_beta) if (ctx.deferred and need_dx) else None
+        wsb = hip.query('tv_gat_layer_workspace_bytes', rows, k, heads, feats, g.num_edges)
+        ws = _workspace(wsb, dev)
+        hip.call('tv_gat_layer_train_bwd', rows, k, heads, feats, g.num_edges, hip.ptr(g.indptr),
+                 hip.ptr(g.indices), hip.ptr(g.rev), hip.ptr(x), x.stride(0), hip.ptr(coeffs),
+                 hip.ptr(in_gamma), hip.ptr(in_beta), ctx.slope, hip.ptr(ctx.row_weight), ctx.count,
+                 hip.ptr(weight), hip.ptr(al), hip.ptr(ar), hip.ptr(wx), hip.ptr(ft), hip.ptr(alpha),
+                 hip.ptr(dout), ctx.x_max.slots.data_ptr(), 2 if ctx.x_max.valid else 1,
+                 ctx.w_max.slots.data_ptr(), 2 if ctx.w_max.valid else 1, int(need_dx), int(need_dw),
+                 hip.ptr(dwx), hip.ptr(dal), hip.ptr(dar), hip.ptr(dbias), hip.ptr(dx),
+                 hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), wsb)
+        dw = dwx[:hf] if need_dw else None
+        if need_dw:
+            dal, dar = dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape)
+        return dx, dgamma, dbeta, dw, dal, dar, dbias, None, None, None, None
+
+
+def gat_layer_train(x, weight, attn_l, attn_r, bias, graph: DeviceGraph,
+                    deferred: Optional[DeferredInput] = None, slope: float = 0.01,
+                    stats_row_weight=None):
+    """`(out, stats_partial)` of one GAT layer in training mode: fc (+ the deferred BatchNorm +
+    LeakyReLU of its input) -> attention scores -> aggregation with column statistics of `out`."""
+    return _GATLayerTrain.apply(x, deferred.gamma if deferred else None,
+                                deferred.beta if deferred else None, weight, attn_l, attn_r, bias,
+                                graph, deferred, slope, stats_row_weight)
 
 
 # ---------------------------------------------------------------------------------------
