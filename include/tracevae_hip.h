@@ -276,6 +276,8 @@ int tv_colsum(int64_t rows, int64_t cols, const float *x, int64_t ldx, float *ou
  * ---------------------------------------------------------------------------------- */
 int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_feats, const float *weight,
                            const float *attn_l, const float *attn_r, float *weight_ext,
+                           float *weight_ext_max, /* nullable: TV_GEMM_MAX_SLOTS partial maxima of
+                                                     |weight_ext|, for tv_gemm_f32_ex state 2 */
                            void *stream);
 int tv_gat_fc_score_weight_bwd(int64_t heads, int64_t feats, int64_t in_feats,
                                const float *weight, const float *attn_l, const float *attn_r,

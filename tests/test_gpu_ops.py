@@ -1214,7 +1214,9 @@ def test_operand_maxima_from_the_producing_kernels(device):
         before = dict(ops.OPERAND_SCANS)
         y = ops.linear_scores(out, w2, al, ar)
         assert hip.lib().tv_gemm_f32_last_form() == 1
-        assert ops.OPERAND_SCANS['kept'] == before['kept'] + 1           # out: kept; weights: scanned
+        # out: from the aggregation; the extended weights: from the kernel that wrote them
+        assert ops.OPERAND_SCANS['kept'] == before['kept'] + 2
+        assert ops.OPERAND_SCANS['scanned'] == before['scanned']
         assert torch.equal(y, ops.linear_scores(out.clone(), w2, al, ar))
         out.add_(1.0)                                  # written to: the maxima no longer apply
         assert ops.operand_max(out) is None

@@ -951,8 +951,10 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
                                                                    const float *__restrict__ W,
                                                                    const float *__restrict__ al,
                                                                    const float *__restrict__ ar,
-                                                                   float *__restrict__ Wx) {
+                                                                   float *__restrict__ Wx,
+                                                                   float *__restrict__ w_max) {
   __shared__ float part[2][16][64];
+  float wmx = 0.f;                                 // max |entry| of what this thread writes
   const int kx = threadIdx.x & 63, fg = threadIdx.x >> 6;      // 64 columns x 16 row groups
   const int h = blockIdx.y;
   const int64_t k = (int64_t)blockIdx.x * 64 + kx;
@@ -970,6 +972,7 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         xp[(int64_t)(f + 16 * u) * K] = w[u];
+        wmx = fmaxf(wmx, fabsf(w[u]));
         sl = fmaf(al[h * F + f + 16 * u], w[u], sl);
         sr = fmaf(ar[h * F + f + 16 * u], w[u], sr);
       }
@@ -977,6 +980,7 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
     for (; f < F; f += 16) {
       const float w = wp[(int64_t)f * K];
       xp[(int64_t)f * K] = w;
+      wmx = fmaxf(wmx, fabsf(w));
       sl = fmaf(al[h * F + f], w, sl);
       sr = fmaf(ar[h * F + f], w, sr);
     }
@@ -988,6 +992,13 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
     float t = 0.f;
     for (int g = 0; g < 16; ++g) t += part[fg][g][kx];
     Wx[((int64_t)H * F + fg * H + h) * K + k] = t;
+    wmx = fmaxf(wmx, fabsf(t));
+  }
+  if (w_max) {                                     // for the fp16 GEMM forms (tv_gemm_f32_ex, state 2)
+    wmx = tv_wave_max(wmx);
+    if (kx == 0)
+      atomicMax(reinterpret_cast<unsigned *>(w_max) + ((blockIdx.x + gridDim.x * blockIdx.y) & 255),
+                __float_as_uint(wmx));
   }
   // rows that pad 2H up to a multiple of 4 (rows of [ft | el | er] stay 16-byte aligned)
   const int pad = ((2 * H + 3) & ~3) - 2 * H;
@@ -1043,13 +1054,15 @@ extern "C" int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const f
 
 extern "C" int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_feats,
                                       const float *weight, const float *attn_l,
-                                      const float *attn_r, float *weight_ext, void *stream) {
+                                      const float *attn_r, float *weight_ext, float *weight_ext_max,
+                                      void *stream) {
   if (int rc = check_shape("tv_gat_fc_score_weight", 0, 1, heads, feats)) return rc;
   TV_REQUIRE(in_feats >= 1, "tv_gat_fc_score_weight: in_feats must be positive");
   TV_REQUIRE(weight && attn_l && attn_r && weight_ext, "tv_gat_fc_score_weight: null pointer");
   const dim3 grid((unsigned)tv_cdiv(in_feats, 64), (unsigned)heads), block(1024);
+  if (weight_ext_max) TV_HIP(hipMemsetAsync(weight_ext_max, 0, 256 * sizeof(float), (hipStream_t)stream));
   hipLaunchKernelGGL(gat_fc_score_weight_kernel, grid, block, 0, (hipStream_t)stream, (int)heads,
-                     (int)feats, in_feats, weight, attn_l, attn_r, weight_ext);
+                     (int)feats, in_feats, weight, attn_l, attn_r, weight_ext, weight_ext_max);
   TV_LAUNCH_CHECK("tv_gat_fc_score_weight");
   return TV_OK;
 }

@@ -35,7 +35,7 @@ int tv_bn_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float *dy,
                     float *dbeta, void *workspace, int64_t workspace_bytes, void *stream);
 int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_feats, const float *weight,
                            const float *attn_l, const float *attn_r, float *weight_ext,
-                           void *stream);
+                           float *weight_ext_max, void *stream);
 int tv_gat_fc_score_weight_bwd(int64_t heads, int64_t feats, int64_t in_feats,
                                const float *weight, const float *attn_l, const float *attn_r,
                                float *dweight_ext, float *dattn_l, float *dattn_r, void *stream);
@@ -123,11 +123,11 @@ extern "C" int tv_gat_layer_train_fwd(
     x_max_state = bound ? 2 : 1;
     scale = sc; shift = sh;
   }
-  if (int rc = tv_gat_fc_score_weight(heads, feats, in_feats, weight, attn_l, attn_r, weight_ext, stream))
+  if (int rc = tv_gat_fc_score_weight(heads, feats, in_feats, weight, attn_l, attn_r, weight_ext, w_max, stream))
     return rc;
   if (int rc = tv_gemm_f32_ex(0, 1, rows, width, in_feats, x, x_stride, weight_ext, in_feats, ft, width,
                               nullptr, nullptr, 0, deferred ? 1 : 0, scale, shift, slope, x_max,
-                              x_max_state, w_max, 1, workspace, workspace_bytes, stream))
+                              x_max_state, w_max, 2, workspace, workspace_bytes, stream))
     return rc;
   if (int rc = tv_gat_aggregate_fwd(rows, 1, heads, feats, indptr, indices, ft, ft + hf, ft + hf + heads,
                                     bias, out, alpha, out_stats, out_stats ? stats_row_weight : nullptr,

@@ -286,9 +286,10 @@ def score_columns(heads: int) -> int:
     return (2 * heads + 3) // 4 * 4
 
 
-def gat_fc_score_weight(weight, attn_l, attn_r):
+def gat_fc_score_weight(weight, attn_l, attn_r, w_max=None):
     """[W ; A_l W ; A_r W] (`tv_gat_fc_score_weight`): the fc weight of a GAT layer with 2H more
-    rows, so that el / er are 2H more columns of the fc product."""
+    rows, so that el / er are 2H more columns of the fc product.  `w_max` (an `OperandMax`)
+    receives the maxima of the result."""
     weight = _check(weight, 'weight')
     heads, feats = int(attn_l.shape[-2]), int(attn_l.shape[-1])
     n, k = weight.shape
@@ -296,7 +297,10 @@ def gat_fc_score_weight(weight, attn_l, attn_r):
         raise ValueError(f'gat_fc_score_weight: weight {tuple(weight.shape)} vs heads {heads} x feats {feats}')
     out = torch.empty([n + score_columns(heads), k], dtype=_f32, device=weight.device)
     hip.call('tv_gat_fc_score_weight', heads, feats, k, hip.ptr(weight),
-             hip.ptr(_check(attn_l, 'attn_l')), hip.ptr(_check(attn_r, 'attn_r')), hip.ptr(out))
+             hip.ptr(_check(attn_l, 'attn_l')), hip.ptr(_check(attn_r, 'attn_r')), hip.ptr(out),
+             None if w_max is None else w_max.slots.data_ptr())
+    if w_max is not None:
+        w_max.valid = True
     return out
 
 
@@ -323,12 +327,12 @@ class _LinearScores(Function):
     def forward(ctx, x, weight, attn_l, attn_r):
         x2 = _check(x, 'x')
         weight = _check(weight, 'weight')
-        wx = gat_fc_score_weight(weight, attn_l, attn_r)
+        ctx.w_max = OperandMax(x2.device)
+        wx = gat_fc_score_weight(weight, attn_l, attn_r, ctx.w_max)
         ctx.save_for_backward(x2, weight, wx, attn_l, attn_r)
         # x and the weights enter the backward pass's products again: their maxima are kept
         need = any(ctx.needs_input_grad)
         ctx.x_max = (operand_max(x) if x2 is x else None) or (OperandMax(x2.device) if need else None)
-        ctx.w_max = OperandMax(x2.device) if need else None
         return gemm(x2, wx, False, True, a_max=ctx.x_max, b_max=ctx.w_max)
 
     @staticmethod
@@ -652,7 +656,7 @@ class _GATLayerTrain(Function):
                  w_max.slots.data_ptr(), hip.ptr(ws), wsb)
         form = int(hip.lib().tv_gemm_f32_last_form())
         x_max.valid = x_max.valid or form != 0 or (d is not None and k <= 2048)
-        w_max.valid = form != 0
+        w_max.valid = True          # written with weight_ext
         ctx.save_for_backward(x, wx, ft, alpha, weight, al, ar,
                               *((coeffs, in_gamma, in_beta) if d else ()))
         ctx.graph, ctx.dims = graph, (rows, k, heads, feats)
@@ -794,9 +798,9 @@ class _BNLReLULinear(Function):
         ctx.x_max.valid = bound_ok
         # with attention vectors: [ft | el | er], as `_LinearScores`
         ctx.scores = attn_l is not None
-        w_fwd = gat_fc_score_weight(weight, attn_l, attn_r) if ctx.scores else weight
         need = any(ctx.needs_input_grad)
-        ctx.w_max = OperandMax(dev) if need else None
+        ctx.w_max = OperandMax(dev) if (need or ctx.scores) else None
+        w_fwd = gat_fc_score_weight(weight, attn_l, attn_r, ctx.w_max) if ctx.scores else weight
         ft = gemm(x, w_fwd, False, True, act=(1, scale, shift, slope), a_max=ctx.x_max,
                   b_max=ctx.w_max)
         if ctx.scores:
