@@ -279,3 +279,26 @@ def test_rccl_code_path_with_one_rank(device, tmp_path):
     out = torch.load(tmp_path / 'rccl1.pt', weights_only=False)
     assert out[False] == (True, True) and out[True] == (True, True), out
     assert out['nan'] and out['aux'], out
+
+
+def test_early_stopping_restores_the_best_validation_epoch(device, tmp_path):
+    """`--train.use_early_stopping=true` (train.py:443-448, mltk EarlyStopping on val_loss): the
+    state of the epoch with the smallest validation loss is what `final.pt` holds and what the
+    final scoring runs on; without the flag it is the last epoch's."""
+    from tracevae_amd.train import fit
+    cfg = _fit_config()
+    cfg.train.max_epoch, cfg.train.struct_pretrain_epochs = 4, 2
+    cfg.train.use_early_stopping = True
+    lines = []
+    out = str(tmp_path / 'es')
+    result = fit(cfg, _fit_stores(), V, out, log=lines.append)
+    best = result['early_stopping_epoch']
+    vals = [float(l.split('val_loss')[1].split()[0]) for l in lines
+            if 'val_loss' in l and 'early stopping' not in l]
+    assert len(vals) == 4 and best == int(np.argmin(vals)) + 1
+    assert any('early stopping: restoring' in l for l in lines)
+    final = torch.load(os.path.join(out, 'models', 'final.pt'), weights_only=True)
+    kept = torch.load(os.path.join(out, 'early-stopping', 'best.pt'), weights_only=True)
+    epoch_file = torch.load(os.path.join(out, 'models', f'{best}.pt'), weights_only=True)
+    for k, v in final.items():
+        assert torch.equal(v, kept[k]) and torch.equal(v, epoch_file[k]), k
