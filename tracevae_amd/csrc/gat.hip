@@ -946,38 +946,40 @@ int check_strides(const char *name, int64_t heads, int64_t feats, const float *f
 // rows to a multiple of 4), row H*F + h =
 // sum_f attn_l[h, f] W[h*F + f, :] (then attn_r), so that el = ft . attn_l = x . (W^T attn_l)
 // and er come out of the fc product itself as 2H more columns and the rows of ft are not read
-// again to form them.  A workgroup owns 64 columns k of one head, 16 row groups deep.
+// again to form them.  A workgroup owns 16 columns k of one head, 64 row groups deep (64-byte
+// row segments; with 64 columns per workgroup a 1000-wide layer filled 32 of the 256 CUs and the
+// launch took 13 us of every layer's forward pass).
+constexpr int SW_COLS = 16, SW_GROUPS = 64;
 __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F, int64_t K,
                                                                    const float *__restrict__ W,
                                                                    const float *__restrict__ al,
                                                                    const float *__restrict__ ar,
                                                                    float *__restrict__ Wx,
                                                                    float *__restrict__ w_max) {
-  __shared__ float part[2][16][64];
+  __shared__ float part[2][SW_GROUPS][SW_COLS];
   float wmx = 0.f;                                 // max |entry| of what this thread writes
-  const int kx = threadIdx.x & 63, fg = threadIdx.x >> 6;      // 64 columns x 16 row groups
+  const int kx = threadIdx.x % SW_COLS, fg = threadIdx.x / SW_COLS;
   const int h = blockIdx.y;
-  const int64_t k = (int64_t)blockIdx.x * 64 + kx;
+  const int64_t k = (int64_t)blockIdx.x * SW_COLS + kx;
   float sl = 0.f, sr = 0.f;
   if (k < K) {
-    // eight rows in flight per thread: with 16 x H x K/64 workgroups the kernel is bound by the
-    // latency of its loads, not by bytes
+    // eight rows in flight per thread: the kernel is bound by the latency of its loads
     const float *wp = W + (int64_t)h * F * K + k;
     float *xp = Wx + (int64_t)h * F * K + k;
     int f = fg;
-    for (; f + 7 * 16 < F; f += 8 * 16) {
+    for (; f + 7 * SW_GROUPS < F; f += 8 * SW_GROUPS) {
       float w[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = wp[(int64_t)(f + 16 * u) * K];
+      for (int u = 0; u < 8; ++u) w[u] = wp[(int64_t)(f + SW_GROUPS * u) * K];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        xp[(int64_t)(f + 16 * u) * K] = w[u];
+        xp[(int64_t)(f + SW_GROUPS * u) * K] = w[u];
         wmx = fmaxf(wmx, fabsf(w[u]));
-        sl = fmaf(al[h * F + f + 16 * u], w[u], sl);
-        sr = fmaf(ar[h * F + f + 16 * u], w[u], sr);
+        sl = fmaf(al[h * F + f + SW_GROUPS * u], w[u], sl);
+        sr = fmaf(ar[h * F + f + SW_GROUPS * u], w[u], sr);
       }
     }
-    for (; f < F; f += 16) {
+    for (; f < F; f += SW_GROUPS) {
       const float w = wp[(int64_t)f * K];
       xp[(int64_t)f * K] = w;
       wmx = fmaxf(wmx, fabsf(w));
@@ -990,13 +992,13 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
   __syncthreads();
   if (fg < 2 && k < K) {                           // row groups summed in order
     float t = 0.f;
-    for (int g = 0; g < 16; ++g) t += part[fg][g][kx];
+    for (int g = 0; g < SW_GROUPS; ++g) t += part[fg][g][kx];
     Wx[((int64_t)H * F + fg * H + h) * K + k] = t;
     wmx = fmaxf(wmx, fabsf(t));
   }
   if (w_max) {                                     // for the fp16 GEMM forms (tv_gemm_f32_ex, state 2)
     wmx = tv_wave_max(wmx);
-    if (kx == 0)
+    if ((threadIdx.x & 63) == 0)
       atomicMax(reinterpret_cast<unsigned *>(w_max) + ((blockIdx.x + gridDim.x * blockIdx.y) & 255),
                 __float_as_uint(wmx));
   }
@@ -1059,7 +1061,7 @@ extern "C" int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_f
   if (int rc = check_shape("tv_gat_fc_score_weight", 0, 1, heads, feats)) return rc;
   TV_REQUIRE(in_feats >= 1, "tv_gat_fc_score_weight: in_feats must be positive");
   TV_REQUIRE(weight && attn_l && attn_r && weight_ext, "tv_gat_fc_score_weight: null pointer");
-  const dim3 grid((unsigned)tv_cdiv(in_feats, 64), (unsigned)heads), block(1024);
+  const dim3 grid((unsigned)tv_cdiv(in_feats, SW_COLS), (unsigned)heads), block(1024);
   if (weight_ext_max) TV_HIP(hipMemsetAsync(weight_ext_max, 0, 256 * sizeof(float), (hipStream_t)stream));
   hipLaunchKernelGGL(gat_fc_score_weight_kernel, grid, block, 0, (hipStream_t)stream, (int)heads,
                      (int)feats, in_feats, weight, attn_l, attn_r, weight_ext, weight_ext_max);

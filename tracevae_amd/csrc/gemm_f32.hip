@@ -1625,7 +1625,9 @@ int64_t choose_splits(int64_t m, int64_t n, int64_t k) {
   if (tiles >= 256 || k < 4 * BK) return 1;
   // one round of the persistent grid: more, shorter units only add slab traffic and epilogues
   // (512 units -> 256: +2.7 % on the 1000 x 1000 x 51200 weight gradients)
-  int64_t s = tv_cdiv(resident_workgroups(), tiles);
+  // (floor: 208 tiles split in two are 416 units, a full round and a partial one of half the
+  // length each - the time of the one unsplit round plus the slabs and their reduction)
+  int64_t s = resident_workgroups() / tiles;
   // a workgroup alone on its CU pays the full memory latency per k-tile, so few-tile problems
   // are split deep: at least 2 k-tiles per split
   constexpr int64_t min_tiles = 2;
