@@ -477,6 +477,15 @@ int tv_adj_bernoulli_ll_bwd(int64_t n_samples, int64_t batch, int64_t max_node_c
                             float alpha, float log_threshold, const float *dll, float *dh,
                             void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The logits of p(adj|z) as a tensor: edge_logits_by_dot_product + dense_to_triu
+ * (tensor_utils.py:54-67, model/struct_vae.py:281-282) for the callers that need the values
+ * themselves - `make_graph` draws the adjacency from them when p() runs without an observed
+ * graph (model/struct_vae.py:296-333), and `.distribution.logits` of the adj node.
+ * logits[g, t] = <h[g,i,:], h[g,j,:]> for the t-th pair i < j in dense_to_triu order; fp32 fma
+ * chain over dim.  graphs <= 65535 per call, max_node_count <= 1536. */
+int tv_edge_logits_triu(int64_t graphs, int64_t max_node_count, int64_t dim, const float *h,
+                        float *logits, void *stream);
+
 /* No counterpart in the reference: tv_adj_bernoulli_ll_fwd for callers that cannot allocate
  * device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc).  Same inputs, outputs and results, no workspace argument: the partial sums live

@@ -157,17 +157,35 @@ def test_train_step_loss_and_gradients(device, V, M, width, layers, batch, extra
         # side (the padded-row form of the same decoder lands on the fp64 side: 2e-6), and
         # with 5 traces a single element of a row that stands for ~400 padded slots is a
         # visible share of a column sum.  Such tensors are held to LONG_TRACE_FLIP_TOL.
+        # The same decision can fall the other way at ANY size (seen once at the 'mid' case
+        # after the split-K rule of the GEMM changed its summation order: feature 305 of the
+        # struct encoder's last BatchNorm bias off by 3.7e-4, every other element of that
+        # tensor within 1.2e-7, and the fc weight's error confined to row 305).  The rule is
+        # therefore tied to its signature, not to a case: a BatchNorm bias gradient (a plain
+        # column sum of the LeakyReLU-gated output gradient) in which ONE element is off and the
+        # next-worst element is at least 20 times closer.  Only then are the tensors above the
+        # bound held to LONG_TRACE_FLIP_TOL instead.
+        flipped = []
+        for n, p in vae.named_parameters():
+            if n.endswith('normalization.bias'):
+                d = (p.grad.double().cpu() - wants[n]).abs().reshape(-1)
+                if d.numel() >= 2:
+                    top = torch.topk(d, 2).values
+                    wmax = float(wants[n].abs().max())
+                    if float(top[0]) > 0.5 * GRAD_TOL * wmax and float(top[0]) > 20.0 * float(top[1]):
+                        flipped.append(n)
         still = []
         for n, (err, wmax) in bad.items():
             err32 = float((P32[n].grad.double() - P[n].grad).abs().max()) / max(wmax, ZERO_GRAD_NOISE * gmax)
-            if not (err < 2.0 * err32 or (V > 5000 and err < LONG_TRACE_FLIP_TOL)):
+            if not (err < 2.0 * err32 or ((V > 5000 or flipped) and err < LONG_TRACE_FLIP_TOL)):
                 still.append((n, err, err32, wmax, gmax))
         if os.path.isdir('gpurun_out'):
             with open(f'gpurun_out/grad_bad_{V}_{batch}.txt', 'w') as f:
                 f.write('\n'.join(f'{n} hip {e:.3e} wmax {w:.3e}' for n, (e, w) in bad.items()))
-                f.write('\nSTILL\n' + '\n'.join(map(str, still)))
+                f.write('\nFLIPPED ' + ' '.join(flipped) + '\nSTILL\n' + '\n'.join(map(str, still)))
         assert not still, sorted(still, key=lambda b: -b[1])[:8]
-        assert V > 5000, ('only the long-trace case is known to need the second arbiter', bad)
+        assert V > 5000 or flipped, ('tensors above the bound without the signature of a '
+                                     'LeakyReLU decision at a zero pre-activation', bad)
     # BatchNorm running statistics moved the same way
     sd = vae.state_dict()
     for k, v in buf.items():

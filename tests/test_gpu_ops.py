@@ -803,6 +803,19 @@ def test_adj_bernoulli_ll(device, M, D, K, biased):
     assert rel_err(hd.grad, hr.grad) < 5 * TOL
 
 
+@pytest.mark.parametrize('M,D,G', [(2, 3, 1), (16, 10, 7), (100, 10, 128), (129, 24, 3), (500, 40, 2)])
+def test_edge_logits_triu(device, M, D, G):
+    """`tv_edge_logits_triu` against dense_to_triu(h h^T) (tensor_utils.py:54-67): every pair in
+    the oracle's order, values to fp32 rounding of a D-term dot product."""
+    from oracle.model import dense_to_triu
+    from tracevae_amd import ops
+    h = _rand(G, M, D, seed=5, scale=0.7)
+    ref = dense_to_triu(h @ h.transpose(-1, -2), M)
+    got = ops.edge_logits_triu(_dev(h, device))
+    assert got.shape == (G, M * (M - 1) // 2)
+    assert rel_err(got, ref) < 1e-6
+
+
 @pytest.mark.parametrize('V,biased', [(1001, False), (33, True), (1488, False),
                                       (10001, False)])       # configs[4]: 10k-operation vocabulary
 def test_categorical_ll(device, V, biased):

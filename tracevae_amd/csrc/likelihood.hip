@@ -567,6 +567,49 @@ static int adj_fwd_launch(int64_t n_samples, int64_t batch, int64_t M, int64_t d
   return TV_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// tv_edge_logits_triu: the logits themselves, for the callers that need them as a tensor (the
+// prior-sampling path draws the adjacency from them; `.distribution.logits` of the adj node).
+// One thread per pair (i < j) of a graph, in dense_to_triu order; fp32 fma chain over dim.
+// ------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void edge_logits_triu_kernel(int64_t graphs, int M, int D,
+                                                               const float *__restrict__ h,
+                                                               float *__restrict__ out) {
+  const int64_t T = (int64_t)M * (M - 1) / 2;
+  const int64_t g = blockIdx.y;
+  const float *hg = h + g * (int64_t)M * D;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    // row i of pair t: the largest i with i*(2M-i-1)/2 <= t
+    int i = (int)((2.0 * M - 1.0 - sqrt((2.0 * M - 1.0) * (2.0 * M - 1.0) - 8.0 * (double)t)) * 0.5);
+    while (i > 0 && (int64_t)i * (2 * M - i - 1) / 2 > t) --i;
+    while ((int64_t)(i + 1) * (2 * M - i - 2) / 2 <= t) ++i;
+    const int j = (int)(t - (int64_t)i * (2 * M - i - 1) / 2) + i + 1;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc = fmaf(hg[(int64_t)i * D + d], hg[(int64_t)j * D + d], acc);
+    out[g * T + t] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int tv_edge_logits_triu(int64_t graphs, int64_t max_node_count, int64_t dim,
+                                   const float *h, float *logits, void *stream) {
+  TV_REQUIRE(graphs >= 0 && graphs <= 65535, "tv_edge_logits_triu: graphs must be in [0, 65535]: got %lld",
+             (long long)graphs);
+  TV_REQUIRE(max_node_count >= 2 && max_node_count <= 1536 && dim >= 1,
+             "tv_edge_logits_triu: bad sizes (max_node_count in [2, 1536], dim >= 1)");
+  if (graphs == 0) return TV_OK;
+  TV_REQUIRE(h && logits, "tv_edge_logits_triu: null pointer");
+  const int64_t T = max_node_count * (max_node_count - 1) / 2;
+  int64_t bx = tv_cdiv(T, 256);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(edge_logits_triu_kernel, dim3((unsigned)bx, (unsigned)graphs), dim3(256), 0,
+                     (hipStream_t)stream, graphs, (int)max_node_count, (int)dim, h, logits);
+  TV_LAUNCH_CHECK("tv_edge_logits_triu");
+  return TV_OK;
+}
+
 extern "C" int tv_adj_bernoulli_ll_fwd(int64_t n_samples, int64_t batch, int64_t max_node_count,
                                        int64_t dim, const float *h, const float *adj, int biased,
                                        float alpha, float log_threshold, float *ll,

@@ -612,9 +612,7 @@ class TraceStructVAE(nn.Module):
         lp = ops.adj_bernoulli_ll(h, batch.adj, n_rep, use_biased, float(M), 0.5)
 
         def edge_logits():
-            full = torch.matmul(h, h.transpose(-1, -2))
-            iu = torch.triu_indices(M, M, 1, device=h.device)
-            return full[:, iu[0], iu[1]].reshape(lead + (-1,))
+            return ops.edge_logits_triu(h).reshape(lead + (-1,))
 
         net.add_node('adj', StochasticTensor(
             batch.adj,
@@ -685,8 +683,7 @@ class TraceStructVAE(nn.Module):
         # adj ~ p(adj | z)
         h = self.pG_node_embedding(self.pG_graph_embedding(z2d))
         h = h.reshape(-1, M, dec.latent_embedding_size)
-        iu = torch.triu_indices(M, M, 1, device=dev)
-        edge_logits = torch.matmul(h, h.transpose(-1, -2))[:, iu[0], iu[1]]
+        edge_logits = ops.edge_logits_triu(h)
         adj = draw('adj', lambda: torch.bernoulli(torch.sigmoid(edge_logits)))
         adj = adj.reshape(graphs, -1).to(torch.float32).contiguous()
         lp = ops.adj_bernoulli_ll(h, adj, 1, use_biased, float(M), 0.5)

@@ -1092,6 +1092,19 @@ def adj_bernoulli_ll(h, adj, n_samples: int, biased: bool = False, alpha: float 
     return _AdjLL.apply(h, adj, n_samples, biased, alpha, math.log(threshold))
 
 
+def edge_logits_triu(h: torch.Tensor) -> torch.Tensor:
+    """[graphs, M, D] -> [graphs, M(M-1)/2]: edge_logits_by_dot_product + dense_to_triu
+    (tensor_utils.py:54-67) as values (`tv_edge_logits_triu`); no gradient - the likelihood and
+    its gradient come from `adj_bernoulli_ll`, which never materialises the logits."""
+    h = _check(h.detach(), 'h')
+    graphs, m, d = h.shape
+    out = torch.empty([graphs, m * (m - 1) // 2], dtype=_f32, device=h.device)
+    for g0 in range(0, graphs, 65535):
+        g1 = min(graphs, g0 + 65535)
+        hip.call('tv_edge_logits_triu', g1 - g0, m, d, hip.ptr(h[g0:g1]), hip.ptr(out[g0:g1]))
+    return out
+
+
 class _CategoricalLL(Function):
     @staticmethod
     def forward(ctx, logits, target, biased: bool, alpha: float, log_thr: float):
