@@ -206,7 +206,7 @@ def cpu_baseline(cfg, flat, lr, V, M, score_k):
     steps, then the median of the timed ones; all host cores, and a one-thread figure.
       training: batch build + forward + backward + clip + RMSprop on the reference's own batch
                 size of 64 traces (train.py:73);
-      scoring:  batch build + encoders + K decoder passes + log-mean-exp on 4 traces."""
+      scoring:  batch build + encoders + K decoder passes + log-mean-exp on 16 traces."""
     from oracle.batching import build_batch
     from oracle.model import OracleTraceVAE
     from tracevae_amd.model import TraceVAE
@@ -252,7 +252,7 @@ def cpu_baseline(cfg, flat, lr, V, M, score_k):
     torch.set_num_threads(threads)
     out['value'], t_train = _median_rate(lambda: train_step(64), 64, 2, 5)
     if score_k > 0:
-        out['scoring_value'], t_score = _median_rate(lambda: score_step(4, score_k), 4, 1, 3)
+        out['scoring_value'], t_score = _median_rate(lambda: score_step(16, score_k), 16, 1, 3)
     torch.set_num_threads(1)
     out['value_1_thread'], t_one = _median_rate(lambda: train_step(8), 8, 1, 3)
     torch.set_num_threads(threads)
@@ -261,7 +261,7 @@ def cpu_baseline(cfg, flat, lr, V, M, score_k):
         f'(batch build + fwd + bwd + clip + RMSprop) on 64 traces, 2 warm-up + 5 timed steps, '
         f'median {1e3 * float(np.median(t_train)):.0f} ms, {threads} threads; one thread: 8 traces, '
         f'1 + 3 steps, median {1e3 * float(np.median(t_one)):.0f} ms'
-        + (f'; scoring K={score_k} on 4 traces, 1 + 3 calls, median '
+        + (f'; scoring K={score_k} on 16 traces, 1 + 3 calls, median '
            f'{1e3 * float(np.median(t_score)):.0f} ms' if score_k > 0 else ''))
     return out
 

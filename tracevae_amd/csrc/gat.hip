@@ -675,7 +675,7 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_bwd_node_kern
 // reads of the same rows meet in the L2; u is its own neighbour through the self-loop) where
 // the two-kernel form read it in both, 205 MB apart.  What cannot ride along is del[u], the sum
 // of dpre over the edges OUT of u: those belong to other rows' softmax and are finished only
-// when the pass is; gat_bwd_score_cols_kernel adds them up afterwards (edge scalars only) and
+// when the pass is; gat_bwd_tail_kernel adds them up afterwards (edge scalars only) and
 // writes the [del | der | 0] columns.
 // ------------------------------------------------------------------------------------
 template <int CH, int HT>
@@ -838,10 +838,10 @@ __global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
 
 // [del | der | 0] behind the HF gradient columns of every dft row: del[u] = sum of dpre over the
 // edges out of u (the opposites, rev[p], of its in-edges), der[u] from the pass above
-__global__ __launch_bounds__(256) void gat_bwd_score_cols_kernel(AggArgs a) {
+__device__ __forceinline__ void gat_bwd_score_cols_block(const AggArgs &a, int64_t block) {
   // four lanes per row, each takes every fourth in-edge (a span has few neighbours: one dependent
   // rev -> dpre chain per lane), summed by two shuffles in a fixed order
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = block * blockDim.x + threadIdx.x;
   const int64_t r = t >> 2;
   const int k = (int)(t & 3);
   const bool live = r < a.rows;
@@ -881,22 +881,39 @@ __global__ __launch_bounds__(256) void gat_bwd_score_cols_kernel(AggArgs a) {
   if (a.out_max) {
     vmax = tv_wave_max(vmax);
     if ((threadIdx.x & 63) == 0)
-      atomicMax(reinterpret_cast<unsigned *>(a.out_max) + (blockIdx.x & 255), __float_as_uint(vmax));
+      atomicMax(reinterpret_cast<unsigned *>(a.out_max) + (block & 255), __float_as_uint(vmax));
   }
 }
 
 // out[s*C + c] = sum_b partial[b][s][c] in workgroup order (float64 accumulation)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t nblk, int64_t sc,
-                                                              const float *__restrict__ partial,
-                                                              float *o0, float *o1, float *o2,
-                                                              int64_t C) {
-  const int64_t i = (int64_t)blockIdx.x * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
+__device__ __forceinline__ void reduce_partials_block(int64_t block, int64_t nblk, int64_t sc,
+                                                      const float *__restrict__ partial,
+                                                      float *o0, float *o1, float *o2, int64_t C) {
+  const int64_t i = block * TV_SLOT_COLS + threadIdx.x % TV_SLOT_COLS;
   double tot[1];
   const int64_t s = i / C, c = i - s * C;
   float *o = (s == 0) ? o0 : (s == 1 ? o1 : o2);
   tv_slot_sums<1>(partial, nblk, sc, 0, i, i < sc && o != nullptr, tot);   // a plane without an
   if (threadIdx.x >= TV_SLOT_COLS || i >= sc) return;                      // output was not written
   if (o) o[c] = (float)tot[0];
+}
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t nblk, int64_t sc,
+                                                              const float *__restrict__ partial,
+                                                              float *o0, float *o1, float *o2,
+                                                              int64_t C) {
+  reduce_partials_block(blockIdx.x, nblk, sc, partial, o0, o1, o2, C);
+}
+// What follows the fused backward pass, as ONE launch (both are a few microseconds of work and
+// independent of each other): workgroups [0, cols_blocks) write the [del | der | 0] columns,
+// the rest add up the bias-gradient partials.
+__global__ __launch_bounds__(256) void gat_bwd_tail_kernel(AggArgs a, int64_t cols_blocks,
+                                                           int64_t nblk, int64_t sc, float *dbias,
+                                                           int64_t C) {
+  if ((int64_t)blockIdx.x < cols_blocks)
+    gat_bwd_score_cols_block(a, blockIdx.x);
+  else
+    reduce_partials_block((int64_t)blockIdx.x - cols_blocks, nblk, sc, a.partial, nullptr, nullptr,
+                          dbias, C);
 }
 
 // launch KERNEL<CH, HT, ...> with CH = 4 or 8 float4 chunks per lane and HT = 1, 2 or MAXH heads
@@ -997,10 +1014,23 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
     wmx = fmaxf(wmx, fabsf(t));
   }
   if (w_max) {                                     // for the fp16 GEMM forms (tv_gemm_f32_ex, state 2)
+    __shared__ float wave_max[16];
     wmx = tv_wave_max(wmx);
-    if ((threadIdx.x & 63) == 0)
-      atomicMax(reinterpret_cast<unsigned *>(w_max) + ((blockIdx.x + gridDim.x * blockIdx.y) & 255),
-                __float_as_uint(wmx));
+    const int nblocks = (int)(gridDim.x * gridDim.y), block = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+    if (nblocks <= 256) {
+      // a slot per workgroup, the rest zeroed here: plain stores, nothing to clear beforehand
+      if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = wmx;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int w = 0; w < 16; ++w) m = fmaxf(m, wave_max[w]);
+        w_max[block] = m;
+      }
+      if (block == 0)
+        for (int sl = nblocks + (int)threadIdx.x; sl < 256; sl += (int)blockDim.x) w_max[sl] = 0.f;
+    } else if ((threadIdx.x & 63) == 0) {          // (the host cleared the slots)
+      atomicMax(reinterpret_cast<unsigned *>(w_max) + (block & 255), __float_as_uint(wmx));
+    }
   }
   // rows that pad 2H up to a multiple of 4 (rows of [ft | el | er] stay 16-byte aligned)
   const int pad = ((2 * H + 3) & ~3) - 2 * H;
@@ -1062,7 +1092,8 @@ extern "C" int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_f
   TV_REQUIRE(in_feats >= 1, "tv_gat_fc_score_weight: in_feats must be positive");
   TV_REQUIRE(weight && attn_l && attn_r && weight_ext, "tv_gat_fc_score_weight: null pointer");
   const dim3 grid((unsigned)tv_cdiv(in_feats, SW_COLS), (unsigned)heads), block(1024);
-  if (weight_ext_max) TV_HIP(hipMemsetAsync(weight_ext_max, 0, 256 * sizeof(float), (hipStream_t)stream));
+  if (weight_ext_max && (int64_t)grid.x * grid.y > 256)
+    TV_HIP(hipMemsetAsync(weight_ext_max, 0, 256 * sizeof(float), (hipStream_t)stream));
   hipLaunchKernelGGL(gat_fc_score_weight_kernel, grid, block, 0, (hipStream_t)stream, (int)heads,
                      (int)feats, in_feats, weight, attn_l, attn_r, weight_ext, weight_ext_max);
   TV_LAUNCH_CHECK("tv_gat_fc_score_weight");
@@ -1205,8 +1236,11 @@ extern "C" int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   if (score_grad_columns) {
     TV_GAT_LAUNCH(gat_bwd_fused_kernel, grid, block, sizeof(float) * HF, s, a);
     TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(fused)");
-    hipLaunchKernelGGL(gat_bwd_score_cols_kernel, dim3((unsigned)tv_cdiv(4 * rows, 256)), dim3(256), 0, s, a);
-    TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(score columns)");
+    const int64_t cols_blocks = tv_cdiv(4 * rows, 256);
+    hipLaunchKernelGGL(gat_bwd_tail_kernel, dim3((unsigned)(cols_blocks + tv_slot_grid(3 * HF))),
+                       dim3(256), 0, s, a, cols_blocks, nblk, 3 * HF, dbias, HF);
+    TV_LAUNCH_CHECK("tv_gat_aggregate_bwd(score columns + bias gradient)");
+    return TV_OK;
   } else {
     // same grid for both passes: they write their column partials into slot blockIdx.x
     TV_GAT_LAUNCH(gat_bwd_edge_kernel, grid, block, sizeof(float) * HF, s, a);
