@@ -406,10 +406,13 @@ int tv_affine_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float 
  * two scalings swapped.  Replaces the update_all(copy_u, sum) of dgl.nn.GraphConv
  * (model/gnn_layers.py:173-183; final decoder layers model/struct_vae.py:201-206,
  * model/latency_vae.py:221-229).
+ * out_max (optional, TV_GEMM_MAX_SLOTS floats; needs cols % 4 == 0, cols >= 64, 16-byte aligned
+ * rows): the partial maxima of |out| for the product that reads `out` next (tv_gemm_f32_ex,
+ * state 2), as tv_gat_aggregate_fwd leaves them.
  * ---------------------------------------------------------------------------------- */
 int tv_graph_sum(int64_t rows_per_rep, int64_t n_rep, int64_t cols, const int64_t *indptr,
                  const int64_t *indices, const float *x, int scale_src, int scale_dst,
-                 float *out, void *stream);
+                 float *out, float *out_max, void *stream);
 /* deg^-1/2 per row of the (replicated) graph, for the GEMM row_scale epilogue */
 int tv_graph_norm(int64_t rows_per_rep, int64_t n_rep, const int64_t *indptr, float *norm,
                   void *stream);

@@ -1233,6 +1233,20 @@ def test_operand_maxima_from_the_producing_kernels(device):
         assert torch.equal(y, ops.linear_scores(out.clone(), w2, al, ar))
         out.add_(1.0)                                  # written to: the maxima no longer apply
         assert ops.operand_max(out) is None
+    # GraphConv: the aggregated rows carry their maxima into the product that follows, which keeps
+    # the maxima of x, of the weights and of the output gradient between its three products
+    wn = (0.05 * rnd(H * F, 52)).requires_grad_(True)          # [in, out], odd class count padded
+    hsrc = rnd(g.num_rows, H * F).requires_grad_(True)
+    agg = ops.graph_sum(hsrc, g)
+    box = ops.operand_max(agg)
+    assert box is not None and float(box.slots.max()) == float(agg.detach().abs().max())
+    before = dict(ops.OPERAND_SCANS)
+    yl = ops.matmul_nn(agg, wn)
+    assert ops.OPERAND_SCANS['kept'] - before['kept'] >= 1     # agg: from the aggregation
+    assert torch.equal(yl.detach(), ops.matmul_nn(agg.detach().clone(), wn.detach()))
+    before = dict(ops.OPERAND_SCANS)
+    yl.backward(rnd(*yl.shape))
+    assert hsrc.grad is not None and wn.grad is not None
     # backward: the gradient rows carry their maxima into the fc layer's two products
     xg = x.clone().requires_grad_(True)
     wg = w.clone().requires_grad_(True)

@@ -14,11 +14,12 @@ __device__ __forceinline__ float deg_norm(const int64_t *indptr, int64_t v) {
 __global__ __launch_bounds__(256) void graph_sum_vec_kernel(
     int64_t rows_per_rep, int64_t rows, int64_t c4, const int64_t *__restrict__ indptr,
     const int64_t *__restrict__ indices, const float *__restrict__ x, int scale_src,
-    int scale_dst, float *__restrict__ out) {
+    int scale_dst, float *__restrict__ out, float *out_max) {
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * nw;
+  float omax = 0.f;
   for (int64_t r = wave; r < rows; r += nwaves) {
     const int64_t rep = r / rows_per_rep, v = r - rep * rows_per_rep, base = rep * rows_per_rep;
     const int64_t p0 = indptr[v], p1 = indptr[v + 1];
@@ -66,10 +67,19 @@ __global__ __launch_bounds__(256) void graph_sum_vec_kernel(
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int64_t q = q0 + lane + 64 * c;
-        if (q < c4)
-          orow[q] = make_float4(acc[c].x * nd, acc[c].y * nd, acc[c].z * nd, acc[c].w * nd);
+        if (q < c4) {
+          const float4 o = make_float4(acc[c].x * nd, acc[c].y * nd, acc[c].z * nd, acc[c].w * nd);
+          orow[q] = o;
+          omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
       }
     }
+  }
+  // partial maxima of |out| for the fp16 GEMM forms that read these rows next (tv_gemm_f32_ex,
+  // state 2): an integer atomic max on the bits of the non-negative float, order-free
+  if (out_max) {
+    omax = tv_wave_max(omax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(out_max) + (blockIdx.x & 255), __float_as_uint(omax));
   }
 }
 
@@ -308,18 +318,22 @@ inline unsigned ew_blocks(int64_t work_items) {
 
 extern "C" int tv_graph_sum(int64_t rows_per_rep, int64_t n_rep, int64_t cols,
                             const int64_t *indptr, const int64_t *indices, const float *x,
-                            int scale_src, int scale_dst, float *out, void *stream) {
+                            int scale_src, int scale_dst, float *out, float *out_max,
+                            void *stream) {
   TV_REQUIRE(rows_per_rep >= 0 && n_rep >= 1 && cols >= 1, "tv_graph_sum: bad sizes");
   const int64_t rows = rows_per_rep * n_rep;
   if (rows == 0) return TV_OK;
   TV_REQUIRE(indptr && indices && x && out, "tv_graph_sum: null pointer");
   TV_REQUIRE(x != out, "tv_graph_sum: in-place aggregation is not possible");
   hipStream_t s = (hipStream_t)stream;
-  if (cols % 4 == 0 && cols >= 64 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0)) {
+  const bool vec = cols % 4 == 0 && cols >= 64 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0);
+  TV_REQUIRE(!out_max || vec, "tv_graph_sum: out_max needs rows of a multiple of 4 floats (>= 64), 16-byte aligned");
+  if (vec) {
     int64_t blocks = tv_cdiv(rows, 4);
     if (blocks > 8192) blocks = 8192;
+    if (out_max) TV_HIP(hipMemsetAsync(out_max, 0, 256 * sizeof(float), s));
     hipLaunchKernelGGL(graph_sum_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rows_per_rep,
-                       rows, cols / 4, indptr, indices, x, scale_src, scale_dst, out);
+                       rows, cols / 4, indptr, indices, x, scale_src, scale_dst, out, out_max);
   } else {
     hipLaunchKernelGGL(graph_sum_scalar_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, s,
                        rows_per_rep, rows, cols, indptr, indices, x, scale_src, scale_dst, out);

@@ -403,22 +403,27 @@ class _MatmulNN(Function):
     """y = x @ W + b with W stored [in, out] (dgl GraphConv weight layout)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        x, weight = _check(x, 'x'), _check(weight, 'weight')
+    def forward(ctx, x_in, weight, bias):
+        x, weight = _check(x_in, 'x'), _check(weight, 'weight')
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return gemm(x, weight, False, False, bias=bias)
+        # x enters this product and the weight gradient, the weights this product and the input
+        # gradient: their maxima (fp16 GEMM forms) are kept between the products
+        ctx.x_max = (operand_max(x_in) if x is x_in else None) or OperandMax(x.device)
+        ctx.w_max = OperandMax(x.device)
+        return gemm(x, weight, False, False, bias=bias, a_max=ctx.x_max, b_max=ctx.w_max)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy_in):
         x, weight = ctx.saved_tensors
-        dy = _rows(dy, 'dy')          # (the categorical log-likelihood hands over padded rows)
+        dy = _rows(dy_in, 'dy')       # (the categorical log-likelihood hands over padded rows)
+        dy_max = (operand_max(dy_in) if dy is dy_in else None) or OperandMax(dy.device)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(dy, weight, False, True)
+            dx = gemm(dy, weight, False, True, a_max=dy_max, b_max=ctx.w_max)
         if ctx.needs_input_grad[1]:
-            dw = gemm(x, dy, True, False)
+            dw = gemm(x, dy, True, False, a_max=ctx.x_max, b_max=dy_max)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)
         return dx, dw, db
@@ -909,8 +914,14 @@ class _GraphSum(Function):
         if rows != graph.num_rows * n_rep:
             raise ValueError(f'graph_sum: {rows} rows do not match graph {graph.num_rows} x {n_rep}')
         out = torch.empty_like(x)
+        # wide rows are the operand of the GraphConv product that follows: their maxima come out
+        # of this pass (`graph_sum` attaches them to the tensor it returns)
+        box = OperandMax(x.device) if (cols % 4 == 0 and cols >= 64) else None
         hip.call('tv_graph_sum', graph.num_rows, n_rep, cols, hip.ptr(graph.indptr),
-                 hip.ptr(graph.indices), hip.ptr(x), int(scale_src), int(scale_dst), hip.ptr(out))
+                 hip.ptr(graph.indices), hip.ptr(x), int(scale_src), int(scale_dst), hip.ptr(out),
+                 None if box is None else box.slots.data_ptr())
+        if box is not None:
+            _LAST_OUT_MAX['graph_sum'] = box
         ctx.graph, ctx.n_rep, ctx.flags = graph, n_rep, (scale_src, scale_dst)
         return out
 
@@ -923,12 +934,16 @@ class _GraphSum(Function):
         dx = torch.empty_like(dout)
         hip.call('tv_graph_sum', g.num_rows, ctx.n_rep, dout.shape[1], hip.ptr(g.indptr),
                  hip.ptr(g.indices), hip.ptr(dout), int(ctx.flags[1]), int(ctx.flags[0]),
-                 hip.ptr(dx))
+                 hip.ptr(dx), None)
         return dx, None, None, None, None
 
 
 def graph_sum(x, graph: DeviceGraph, n_rep: int = 1, scale_src: bool = True, scale_dst: bool = True):
-    return _GraphSum.apply(x, graph, n_rep, scale_src, scale_dst)
+    out = _GraphSum.apply(x, graph, n_rep, scale_src, scale_dst)
+    box = _LAST_OUT_MAX.pop('graph_sum', None)
+    if box is not None:
+        box.attach(out)
+    return out
 
 
 class _SegmentMean(Function):
