@@ -284,6 +284,11 @@ int tv_gat_fc_score_weight_bwd(int64_t heads, int64_t feats, int64_t in_feats,
                                float *dweight_ext, float *dattn_l, float *dattn_r, void *stream);
 int tv_gat_scores(int64_t rows, int64_t heads, int64_t feats, const float *ft,
                   const float *attn_l, const float *attn_r, float *el, float *er, void *stream);
+/* (tv_gat_aggregate_fwd: large inference launches - the [ft | el | er] layout, no statistics,
+ * at least 16384 rows of at most 1024 floats - run on a windowed form of the kernel that stages
+ * 32 consecutive rows per workgroup in LDS and serves the gathers inside the window from there;
+ * bit-equal to the per-row form.  TV_GAT_LDS_MIN_WINDOWS in the environment moves the threshold,
+ * for A/B measurements.) */
 int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int64_t feats,
                          const int64_t *indptr, const int64_t *indices, const float *ft,
                          const float *el, const float *er, const float *bias, float *out,

@@ -1200,6 +1200,52 @@ def test_gemm_operand_maxima_kept_by_the_caller(device):
     assert hip.lib().tv_gemm_f32_last_form() == 0 and not sm.valid
 
 
+@pytest.mark.parametrize('n_rep,epilogue', [(1, True), (3, True), (1, False)])
+def test_gat_forward_windowed_equals_per_row(device, n_rep, epilogue, monkeypatch):
+    """The windowed forward aggregation (32 rows staged in LDS per workgroup; taken for
+    [ft | el | er] rows without statistics from 512 windows on) adds a row's neighbours in the
+    same edge order with the same arithmetic as the per-row kernel: bit-equal outputs and maxima.
+    The graph has chains inside and across windows, a row with 80 in-neighbours outside its
+    window (the three-pass path), rows without in-edges and a row count that is no multiple of
+    the window."""
+    from tracevae_amd import ops
+    H, F = 2, 500
+    R = 16400 // n_rep + 7
+    rng = np.random.RandomState(4)
+    nbrs = [[r] for r in range(R)]                        # self loops
+    for r in range(R - 1):
+        if r % 50 != 49:                                  # chains of 50 rows, both directions
+            nbrs[r].append(r + 1)
+            nbrs[r + 1].append(r)
+    for r in range(0, R - 40, 97):                        # edges that leave the window
+        nbrs[r].append(r + 37)
+    nbrs[7] = [7] + list(range(100, 180))                 # more than 64 in-neighbours
+    nbrs[33] = []                                         # no in-edge at all
+    indptr = np.zeros(R + 1, np.int64)
+    indptr[1:] = np.cumsum([len(x) for x in nbrs])
+    indices = np.concatenate([np.asarray(x, np.int64) for x in nbrs if len(x)])
+    ti = lambda a_: torch.as_tensor(a_).to(device)
+    z = ti(np.zeros(len(indices), np.int64))
+    g = ops.DeviceGraph(ti(indptr), ti(indices), z, z, z, z)
+    gen = torch.Generator().manual_seed(11)
+    ft = torch.randn(R * n_rep, H * F + 4, generator=gen).to(device)
+    al, ar = 0.05 * torch.randn(1, H, F, generator=gen).to(device), 0.05 * torch.randn(1, H, F, generator=gen).to(device)
+    bias = 0.1 * torch.randn(H * F, generator=gen).to(device)
+    sc = (0.5 + torch.rand(H * F, generator=gen)).to(device) if epilogue else None
+    sh = (0.2 * torch.randn(H * F, generator=gen)).to(device) if epilogue else None
+    assert (R * n_rep + 31) // 32 >= 512
+    with torch.no_grad():
+        out_w, _ = ops.gat_conv(ft, al, ar, bias, g, n_rep, ep_scale=sc, ep_shift=sh)
+        monkeypatch.setenv('TV_GAT_LDS_MIN_WINDOWS', '1000000000')
+        out_r, _ = ops.gat_conv(ft, al, ar, bias, g, n_rep, ep_scale=sc, ep_shift=sh)
+    assert torch.equal(out_w, out_r)
+    assert float(out_w[33 if n_rep == 1 else R + 33].abs().max()) == float(
+        out_r[33 if n_rep == 1 else R + 33].abs().max())
+    if epilogue:
+        bw, br = ops.operand_max(out_w), ops.operand_max(out_r)
+        assert float(bw.slots.max()) == float(br.slots.max()) == float(out_r.abs().max())
+
+
 def test_operand_maxima_from_the_producing_kernels(device):
     """The kernels that write a GEMM operand leave its maxima with it: the aggregation with the
     eval epilogue (exact: the next layer's product is bit-equal to one that scans), the backward

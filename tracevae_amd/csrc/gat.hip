@@ -11,6 +11,7 @@
 //
 // HBM-bound.  Algorithmic bytes, forward, per destination row with d in-edges:
 //   4*HF*d (ft gathers) + 4*HF (out) + 8*H*(d+1) (scores) + 8*d (indices) + 4*H*d (alpha).
+#include <cstdlib>
 #include <type_traits>
 
 #include "tv_common.h"
@@ -134,6 +135,7 @@ struct AggArgs {
   const int64_t *indptr, *indices, *rev;
   const float *ft, *el, *er, *bias, *attn_l, *attn_r, *alpha_in, *dout;
   float *out, *alpha, *stats_partial;
+  int64_t stats_slots;       // workgroup slots the caller sized stats_partial for
   const float *row_weight;   // optional weights of the rows in the column statistics
   const float *ep_scale, *ep_shift;
   float ep_slope;
@@ -384,6 +386,312 @@ __global__ __launch_bounds__(512, gat_waves_per_simd(CH)) void gat_aggregate_fwd
 #pragma unroll
     for (int c = 0; c < CH; ++c) { v[0][c] = ssum[c]; v[1][c] = ssq[c]; }
     block_col_reduce<2, CH>(lds, v, c4, a.stats_partial + (int64_t)blockIdx.x * 2 * HF);
+  }
+  if (EPILOGUE && a.out_max) {
+    omax = tv_wave_max(omax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.out_max) + (blockIdx.x & 255), __float_as_uint(omax));
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// forward aggregate, windowed: a workgroup stages LDS_ROWS consecutive [ft | el | er] rows in LDS
+// and serves every gather whose source lies in the window from there.
+//
+// Why: the counters say the per-row kernel above is bound by the read requests a CU can keep in
+// flight (TCP -> L2: 40-70 outstanding per CU in every memory-bound kernel of this library,
+// whatever its structure; latency 660 cycles here), and a row with d in-edges sends d rows
+// through that queue although the L2 serves most of them.  A trace's rows are contiguous and
+// 65 % of its edges join rows less than a 32-row window apart, so the window cuts the rows
+// through the L1 from 2.0 to 1.34 per output row on the decoder graph and from 2.96 to 1.69 on
+// the encoder graph.  The next window's rows are fetched into registers while this window is
+// summed (a plain streaming read: every load of a wave in flight together).
+// Measured (tools/gat_lab.py, 1.28 M rows of K = 100 scoring): 2800 -> 2500 us per launch, K = 100
+// scoring 73.0 -> 71.5 ms on the same box; bit-equal to the per-row kernel (same edge order).
+// Taken for the column layout of tv_gat_fc_score_weight ([ft | el | er] rows), H*F + 2H <= 1024,
+// no column statistics (the training variant needs 32 more registers per lane and spills in
+// this form) and at least 512 windows (TV_GAT_LDS_MIN_WINDOWS in the environment moves that
+// threshold, for A/B runs); everything else stays on the per-row kernel.
+// ------------------------------------------------------------------------------------
+#ifndef TV_GAT_LDS_ROWS
+#define TV_GAT_LDS_ROWS 32
+#endif
+constexpr int LDS_ROWS = TV_GAT_LDS_ROWS;
+constexpr int LDS_WAVES = LDS_ROWS / 2;        // two rows of the window per wave
+constexpr int LDS_WGS_PER_CU = 32 / LDS_ROWS;  // by LDS: 32 rows of 4 KB fill a CU
+
+template <int HT, bool STATS, bool EPILOGUE>
+__global__ __launch_bounds__(64 * LDS_WAVES, 4) void gat_aggregate_fwd_lds_kernel(AggArgs a) {
+  extern __shared__ float lds[];
+  constexpr int CH = 4;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int H = a.H, F = a.F, c4 = a.c4;
+  const int64_t HF = (int64_t)H * F;
+  const int ld4 = (int)(a.ld_ft >> 2);                    // float4 per staged row (<= 256)
+  const int ldf = (int)a.ld_ft, hf = (int)HF;             // (LDS is indexed with 32-bit integers)
+  float4 *win = reinterpret_cast<float4 *>(lds);          // [LDS_ROWS][ld4]
+  float *red = lds + LDS_ROWS * ldf;          // column-statistics scratch (STATS)
+
+  int hc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) hc[c] = ((lane + 64 * c) * 4) / F;
+  float4 ssum[STATS ? CH : 1], ssq[STATS ? CH : 1];
+  if (STATS) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) ssum[c] = ssq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float omax = 0.f;
+
+  // windows: each XCD owns a contiguous eighth of them (see row_walk)
+  const int64_t nwin = (a.rows + LDS_ROWS - 1) / LDS_ROWS;
+  int64_t wbeg, wend, wstep;
+  {
+    const int64_t g = gridDim.x, b = blockIdx.x;
+    if ((g & 7) != 0) { wbeg = b; wend = nwin; wstep = g; }
+    else {
+      const int64_t per = (nwin + 7) >> 3;
+      const int64_t lo = (b & 7) * per;
+      wbeg = lo + (b >> 3); wend = lo + per < nwin ? lo + per : nwin; wstep = g >> 3;
+    }
+  }
+  // the rows of the NEXT window, on their way: two rows per wave
+  float4 pf[2][CH];
+  auto fetch = [&](int64_t wi) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t r = wi * LDS_ROWS + w + LDS_WAVES * j;
+      const float4 *src = reinterpret_cast<const float4 *>(a.ft + (r < a.rows ? r : 0) * a.ld_ft);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        pf[j][c] = (q < ld4 && r < a.rows) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  // the index chain of a row (indptr -> indices -> el) is looked ahead like the rows: (p0, deg)
+  // of the rows two windows on and the neighbour indices of the next window's rows are loaded
+  // while this window is summed, and the el loads of both rows of a wave go out together
+  // (32-bit: a replica has fewer than 2^31 rows and edges, checked on the host)
+  int p0_c[2] = {0, 0}, p0_1[2] = {0, 0}, p0_2[2] = {0, 0}, s_c[2] = {0, 0}, s_1[2] = {0, 0};
+  int deg_c[2] = {0, 0}, deg_1[2] = {0, 0}, deg_2[2] = {0, 0};
+  auto load_pd = [&](int64_t wi, int j, int &p0, int &deg) {
+    // (no branch: the loads of a window are a fixed sequence, so that the wait for the FIRST of
+    // them - the el values the sums start with - can leave every later one in flight; on gfx9 a
+    // wave's loads return in order and a wait is a count of the younger ones)
+    const int64_t r = wi * LDS_ROWS + w + LDS_WAVES * j;
+    const int64_t v = (r < a.rows ? r : a.rows - 1) % a.rows_per_rep;
+    p0 = (int)a.indptr[v];
+    deg = (r < a.rows) ? (int)a.indptr[v + 1] - p0 : 0;
+  };
+  if (wbeg < wend) {
+    fetch(wbeg);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      load_pd(wbeg, j, p0_c[j], deg_c[j]);
+      s_c[j] = (lane < deg_c[j]) ? (int)a.indices[p0_c[j] + lane] : 0;
+      if (wbeg + wstep < wend) load_pd(wbeg + wstep, j, p0_1[j], deg_1[j]);
+    }
+  }
+  for (int64_t wi = wbeg; wi < wend; wi += wstep) {
+    const int64_t r0 = wi * LDS_ROWS;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        if (q < ld4) win[(w + LDS_WAVES * j) * ld4 + q] = pf[j][c];
+      }
+    __syncthreads();
+    // el of every edge of the wave's two rows first (one edge per lane; rows of more than 64
+    // neighbours read theirs again below), then the look-ahead loads behind them
+    float elv[2][HT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t r = r0 + w + LDS_WAVES * j;
+      const int64_t base = (r < a.rows ? r / a.rows_per_rep : 0) * a.rows_per_rep;
+      const int64_t srow = (lane < deg_c[j] && deg_c[j] <= 64) ? base + s_c[j] : 0;
+#pragma unroll
+      for (int h = 0; h < HT; ++h) elv[j][h] = a.ft[srow * a.ld_ft + HF + (h < H ? h : 0)];
+    }
+    {
+      // (past the last window the same loads go to the last window again and are not used)
+      const int64_t w1 = wi + wstep < wend ? wi + wstep : wi;
+      const int64_t w2 = wi + 2 * wstep < wend ? wi + 2 * wstep : wi;
+      fetch(w1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int lim = wi + wstep < wend ? deg_1[j] : 0;
+        s_1[j] = (int)a.indices[p0_1[j] + (lane < lim ? lane : 0)];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) load_pd(w2, j, p0_2[j], deg_2[j]);
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int lr = w + LDS_WAVES * j;                    // row of the window
+      const int64_t r = r0 + lr;
+      if (r < a.rows) {
+      const int64_t rep = r / a.rows_per_rep;
+      const int64_t v = r - rep * a.rows_per_rep;
+      const int64_t base = rep * a.rows_per_rep;
+      const int64_t p0 = p0_c[j];
+      const int deg = deg_c[j];
+      const float *own = lds + lr * ldf;
+      float erv[HT];
+#pragma unroll
+      for (int h = 0; h < HT; ++h) erv[h] = (h < H) ? own[hf + H + h] : 0.f;
+      float4 acc[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // el of a source row: one float per head and edge, read from memory (an L2 hit; a per-lane
+      // choice between an LDS and a global load does not get through this compiler)
+      auto el_of = [&](int64_t s, int h) -> float { return a.ft[s * a.ld_ft + HF + h]; };
+      auto add_row = [&](int64_t sj, const float (&aj)[HT]) {
+        const int64_t d = sj - r0;                         // wave-uniform
+        if (d >= 0 && d < LDS_ROWS) {
+          const float4 *srow = win + (int)d * ld4;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const int q = lane + 64 * c;
+            if (q < c4) acc[c] = f4_fma(sel_head<HT>(aj, hc[c]), srow[q], acc[c]);
+          }
+        } else {
+          const float4 *srow = reinterpret_cast<const float4 *>(a.ft + sj * a.ld_ft);
+          float4 x[CH];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const int q = lane + 64 * c;
+            x[c] = (q < c4) ? srow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int c = 0; c < CH; ++c) acc[c] = f4_fma(sel_head<HT>(aj, hc[c]), x[c], acc[c]);
+        }
+      };
+      if (deg <= 64) {
+        const bool live = lane < deg;
+        const int64_t s = live ? base + s_c[j] : 0;
+        float e[HT], al[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+          e[h] = (live && h < H) ? tv_lrelu(elv[j][h] + erv[h], NEG_SLOPE) : -INFINITY;
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+          const float mx = tv_wave_max(e[h]);
+          const float ex = live ? expf(e[h] - mx) : 0.f;
+          const float den = tv_wave_sum(ex);
+          al[h] = ex / den;
+          if (a.alpha && live && h < H) a.alpha[(rep * a.num_edges + p0 + lane) * H + h] = al[h];
+        }
+        for (int jj = 0; jj < deg; ++jj) {                 // summed in edge order
+          const int64_t sj = __shfl(s, jj, 64);
+          float aj[HT];
+#pragma unroll
+          for (int h = 0; h < HT; ++h) aj[h] = __shfl(al[h], jj, 64);
+          add_row(sj, aj);
+        }
+      } else {
+        // many neighbours (rare): three passes over the edge list, 64 edges at a time
+        float mx[HT], den[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) { mx[h] = -INFINITY; den[h] = 0.f; }
+        for (int c0 = 0; c0 < deg; c0 += 64) {
+          const int jx = c0 + lane;
+          if (jx < deg) {
+            const int64_t s = base + a.indices[p0 + jx];
+#pragma unroll
+            for (int h = 0; h < HT; ++h)
+              if (h < H) mx[h] = fmaxf(mx[h], tv_lrelu(el_of(s, h) + erv[h], NEG_SLOPE));
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < HT; ++h) mx[h] = tv_wave_max(mx[h]);
+        for (int c0 = 0; c0 < deg; c0 += 64) {
+          const int jx = c0 + lane;
+          if (jx < deg) {
+            const int64_t s = base + a.indices[p0 + jx];
+#pragma unroll
+            for (int h = 0; h < HT; ++h)
+              if (h < H) den[h] += expf(tv_lrelu(el_of(s, h) + erv[h], NEG_SLOPE) - mx[h]);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < HT; ++h) den[h] = tv_wave_sum(den[h]);
+        for (int c0 = 0; c0 < deg; c0 += 64) {
+          const int jx = c0 + lane;
+          int64_t s = 0;
+          float al[HT];
+#pragma unroll
+          for (int h = 0; h < HT; ++h) al[h] = 0.f;
+          if (jx < deg) {
+            s = base + a.indices[p0 + jx];
+#pragma unroll
+            for (int h = 0; h < HT; ++h)
+              if (h < H) {
+                al[h] = expf(tv_lrelu(el_of(s, h) + erv[h], NEG_SLOPE) - mx[h]) / den[h];
+                if (a.alpha) a.alpha[(rep * a.num_edges + p0 + jx) * H + h] = al[h];
+              }
+          }
+          const int cnt = (deg - c0 < 64) ? (deg - c0) : 64;
+          for (int jj = 0; jj < cnt; ++jj) {
+            const int64_t sj = __shfl(s, jj, 64);
+            float aj[HT];
+#pragma unroll
+            for (int h = 0; h < HT; ++h) aj[h] = __shfl(al[h], jj, 64);
+            add_row(sj, aj);
+          }
+        }
+      }
+      // epilogue: + bias, optional fused BatchNorm(eval)+LeakyReLU or column statistics
+      float4 *orow = reinterpret_cast<float4 *>(a.out + r * HF);
+      const float sw = (STATS && a.row_weight) ? a.row_weight[v] : 1.0f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        if (q < c4) {
+          float4 o = f4_add(acc[c], reinterpret_cast<const float4 *>(a.bias)[q]);
+          if (STATS) {
+            const float4 wo = make_float4(sw * o.x, sw * o.y, sw * o.z, sw * o.w);
+            ssum[c] = f4_add(ssum[c], wo);
+            ssq[c] = make_float4(fmaf(wo.x, o.x, ssq[c].x), fmaf(wo.y, o.y, ssq[c].y),
+                                 fmaf(wo.z, o.z, ssq[c].z), fmaf(wo.w, o.w, ssq[c].w));
+          }
+          if (EPILOGUE) {
+            const float4 sc = reinterpret_cast<const float4 *>(a.ep_scale)[q];
+            const float4 sh = reinterpret_cast<const float4 *>(a.ep_shift)[q];
+            o.x = tv_lrelu(fmaf(o.x, sc.x, sh.x), a.ep_slope);
+            o.y = tv_lrelu(fmaf(o.y, sc.y, sh.y), a.ep_slope);
+            o.z = tv_lrelu(fmaf(o.z, sc.z, sh.z), a.ep_slope);
+            o.w = tv_lrelu(fmaf(o.w, sc.w, sh.w), a.ep_slope);
+            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+          }
+          if (EPILOGUE && a.n_rep >= 8) {
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t ov = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t *>(orow + q));
+          } else {
+            orow[q] = o;
+          }
+        }
+      }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      p0_c[j] = p0_1[j]; deg_c[j] = deg_1[j]; s_c[j] = s_1[j];
+      p0_1[j] = p0_2[j]; deg_1[j] = deg_2[j];
+    }
+    __syncthreads();                                       // the window is overwritten next
+  }
+
+  if (STATS) {
+    float4 v[2][CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { v[0][c] = ssum[c]; v[1][c] = ssq[c]; }
+    block_col_reduce<2, CH>(red, v, c4, a.stats_partial + (int64_t)blockIdx.x * 2 * HF);
+    // the caller sized the partials for stats_slots workgroups: the slots behind this grid are zero
+    for (int64_t sl = (int64_t)gridDim.x + blockIdx.x; sl < a.stats_slots; sl += gridDim.x)
+      for (int64_t i = threadIdx.x; i < 2 * HF; i += blockDim.x) a.stats_partial[sl * 2 * HF + i] = 0.f;
   }
   if (EPILOGUE && a.out_max) {
     omax = tv_wave_max(omax);
@@ -931,6 +1239,26 @@ __global__ __launch_bounds__(256) void gat_bwd_tail_kernel(AggArgs a, int64_t co
     }                                                                                            \
   } while (0)
 
+// the windowed forward form needs more than 64 KB of LDS per workgroup: raised once per device
+template <int HT, bool STATS, bool EPILOGUE>
+void launch_lds(dim3 grid, dim3 block, size_t ldsb, hipStream_t s, const AggArgs &a) {
+  static bool raised[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !raised[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gat_aggregate_fwd_lds_kernel<HT, STATS, EPILOGUE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised[dev] = true;
+  }
+  hipLaunchKernelGGL((gat_aggregate_fwd_lds_kernel<HT, STATS, EPILOGUE>), grid, block, ldsb, s, a);
+}
+// fewest 32-row windows for which the windowed form is taken (one workgroup per CU: below a
+// round of the chip the per-row kernel spreads the rows over more waves)
+int64_t gat_lds_min_windows() {
+  const char *e = getenv("TV_GAT_LDS_MIN_WINDOWS");
+  return e ? atoll(e) : 512;
+}
+
 // workgroups of the statistics-free aggregation (the row loop strides over the grid)
 int64_t tv_gat_max_blocks() { return 2048; }
 
@@ -1153,6 +1481,29 @@ extern "C" int tv_gat_aggregate_fwd(int64_t rows_per_rep, int64_t n_rep, int64_t
   a.num_edges = 0;
   hipStream_t s = (hipStream_t)stream;
   const bool big = a.c4 > 256;
+  a.stats_slots = tv_stat_blocks_host(rows);
+  // the windowed form: [ft | el | er] rows of at most 1024 floats, enough windows for the chip
+  const bool columns = el == ft + heads * feats && er == el + heads && score_stride == ft_stride;
+  const int64_t windows = tv_cdiv(rows, LDS_ROWS);
+  // (the statistics variant of a training step keeps 32 more registers per lane and spills in
+  // this form: 117 against 52 us per launch - it stays on the per-row kernel)
+  if (columns && !stats_partial && ft_stride <= 1024 && windows >= gat_lds_min_windows()) {
+    int64_t blocks = windows < 256 * LDS_WGS_PER_CU ? windows : 256 * LDS_WGS_PER_CU;
+    const dim3 grid((unsigned)blocks), block(64 * LDS_WAVES);
+    const size_t ldsb = sizeof(float) * (size_t)LDS_ROWS * ft_stride;
+    const int ht = heads == 1 ? 1 : (heads == 2 ? 2 : MAXH);
+#define TV_GAT_LDS_LAUNCH(ST, EP)                                                                   \
+    do {                                                                                           \
+      if (ht == 1) launch_lds<1, ST, EP>(grid, block, ldsb, s, a);                                 \
+      else if (ht == 2) launch_lds<2, ST, EP>(grid, block, ldsb, s, a);                            \
+      else launch_lds<MAXH, ST, EP>(grid, block, ldsb, s, a);                                      \
+    } while (0)
+    if (ep_scale) TV_GAT_LDS_LAUNCH(false, true);
+    else TV_GAT_LDS_LAUNCH(false, false);
+#undef TV_GAT_LDS_LAUNCH
+    TV_LAUNCH_CHECK("tv_gat_aggregate_fwd(windowed)");
+    return TV_OK;
+  }
   if (stats_partial) {
     const dim3 grid((unsigned)tv_stat_blocks_host(rows)), block(64 * TV_STAT_WAVES);
     const size_t ldsb = sizeof(float) * 2 * heads * feats;
