@@ -436,7 +436,7 @@ def main():
             if a and a[2] > 0:
                 entry = message_passing_entry(
                     'gat_aggregate_fwd', score_kernels, ops.TIMER.by_tag('gat_aggregate_fwd'), dt,
-                    measured_traffic(args, 'gat_aggregate_fwd_kernel', SCORING_TRAFFIC_PROFILE))
+                    measured_traffic(args, 'gat_aggregate_fwd', SCORING_TRAFFIC_PROFILE))
                 ideal += entry['achieved'] * 1e9 * a[2] * 1e-3 / (HBM_PEAK_GBS * 1e9)
                 scoring['gat_aggregate_fwd'] = entry
             scoring['step_roofline'] = {'ideal_ms_per_step': 1e3 * ideal / args.score_steps,
@@ -488,7 +488,7 @@ def main():
             train_gemm_tags, elapsed, measured_traffic(args),
             'bytes/launch (profiles/r03_hbm_traffic.json)', args.steps)
         others = {}
-        pmc_names = {'gat_aggregate_fwd': 'gat_aggregate_fwd_kernel',
+        pmc_names = {'gat_aggregate_fwd': 'gat_aggregate_fwd',
                      'gat_aggregate_bwd': 'gat_bwd_fused_kernel'}
         for name in ('gat_aggregate_fwd', 'gat_aggregate_bwd'):
             if name in kernel_summary and kernel_summary[name][2] > 0:
