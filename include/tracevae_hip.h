@@ -170,6 +170,14 @@ int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int64_t num_ed
  * ---------------------------------------------------------------------------------- */
 int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int tv_gemm_f32_last_form(void);
+/* Measurement aid, no counterpart in the reference.  Between _begin and _end the MAIN kernel of
+ * every product (not the operand scans, the split of B or the reductions around it) is bracketed
+ * by a pair of HIP events on the stream it is launched on.  _end waits for them, writes
+ * [milliseconds, form, m, n, k] as 5 doubles per product in launch order (up to `capacity`
+ * records; `records` is HOST memory) and returns the number of products seen.  bench.py prices
+ * the dominant kernel with it; rocprofv3's per-kernel averages are the cross-check. */
+int tv_gemm_profile_begin(void);
+int64_t tv_gemm_profile_end(double *records, int64_t capacity);
 int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
                 int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc,
                 const float *bias, const float *row_scale, int accumulate, void *workspace,

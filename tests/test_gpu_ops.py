@@ -1246,6 +1246,35 @@ def test_gat_forward_windowed_equals_per_row(device, n_rep, epilogue, monkeypatc
         assert float(bw.slots.max()) == float(br.slots.max()) == float(out_r.abs().max())
 
 
+def test_gemm_profile_records_the_main_kernel_of_every_product(device):
+    """`tv_gemm_profile_begin / _end` (the bench's kernel-alone timing): one record per product in
+    launch order with its form and shape, a positive duration that is shorter than the call's own
+    wall time, nothing recorded outside the bracket."""
+    import time
+    from tracevae_amd import hip, ops
+    a = torch.randn(20000, 512, device=device)
+    w = torch.randn(768, 512, device=device)
+    s = torch.randn(300, 40, device=device)
+    ops.gemm(a, w, False, True)                          # warm-up, outside the bracket
+    hip.lib().tv_gemm_profile_begin()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops.gemm(a, w, False, True)                          # wide form
+    ops.gemm(s, s, True, False)                          # producer / consumer form
+    ops.gemm(a, a, True, False)                          # k-major wide form
+    torch.cuda.synchronize()
+    wall_ms = 1e3 * (time.perf_counter() - t0)
+    buf = np.zeros([8, 5])
+    n = int(hip.lib().tv_gemm_profile_end(buf.ctypes.data, 8))
+    assert n == 3
+    assert [int(f) for f in buf[:3, 1]] == [1, 0, 2]
+    assert [tuple(int(v) for v in r[2:]) for r in buf[:3]] == [(20000, 768, 512), (40, 40, 300),
+                                                               (512, 512, 20000)]
+    assert (buf[:3, 0] > 0).all() and buf[:3, 0].sum() < wall_ms
+    ops.gemm(a, w, False, True)
+    assert int(hip.lib().tv_gemm_profile_end(buf.ctypes.data, 8)) == 0
+
+
 def test_operand_maxima_from_the_producing_kernels(device):
     """The kernels that write a GEMM operand leave its maxima with it: the aggregation with the
     eval epilogue (exact: the next layer's product is bit-equal to one that scans), the backward

@@ -54,7 +54,9 @@
 // is split over K into slabs and summed by a second kernel in slab order (deterministic).
 #include "tv_common.h"
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -1647,6 +1649,38 @@ extern "C" int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) 
 
 namespace {
 thread_local int g_last_form = 0;
+
+// Measurement aid (tv_gemm_profile_begin / _end): while it is on, the MAIN kernel of every product
+// is bracketed by a pair of HIP events on the stream it is launched on - the kernel alone,
+// without the operand scans, the split of B and the reductions around it.
+struct GemmProfileRecord { hipEvent_t start, stop; int form; int64_t m, n, k; };
+struct GemmProfile {
+  std::mutex lock;                  // forward and backward passes come from different threads
+  bool on = false;
+  std::vector<GemmProfileRecord> records;
+} g_profile;
+struct ProfileScope {
+  bool active = false;
+  GemmProfileRecord rec;
+  hipStream_t stream;
+  ProfileScope(hipStream_t s, int form, int64_t m, int64_t n, int64_t k) : stream(s) {
+    std::lock_guard<std::mutex> guard(g_profile.lock);
+    if (!g_profile.on) return;
+    rec.form = form; rec.m = m; rec.n = n; rec.k = k;
+    if (hipEventCreate(&rec.start) != hipSuccess) return;
+    if (hipEventCreate(&rec.stop) != hipSuccess) { (void)hipEventDestroy(rec.start); return; }
+    (void)hipEventRecord(rec.start, stream);
+    active = true;
+  }
+  void done() {
+    if (!active) return;
+    (void)hipEventRecord(rec.stop, stream);
+    std::lock_guard<std::mutex> guard(g_profile.lock);
+    g_profile.records.push_back(rec);
+    active = false;
+  }
+};
+
 int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
              int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, const float *bias,
              const float *row_scale, int accumulate, int act_operand, const float *act_scale,
@@ -1781,8 +1815,10 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
       raised[wa][device & 63] = true;
     }
+    ProfileScope prof(s, 1, m, n, k);
     if (wa) hipLaunchKernelGGL(gemm_wide_h_kernel<true>, dim3((unsigned)units), dim3(512), wlds, s, w);
     else hipLaunchKernelGGL(gemm_wide_h_kernel<false>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    prof.done();
     TV_LAUNCH_CHECK("tv_gemm_f32(wide)");
     if (w.tail_splits > 1) {
       hipLaunchKernelGGL(gemm_wide_tail_reduce_kernel, dim3((unsigned)((plan.w_tiles - w.tail_first) * 8)),
@@ -1825,8 +1861,10 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
       raised[wa][device & 63] = true;
     }
+    ProfileScope prof(s, 2, m, n, k);
     if (wa) hipLaunchKernelGGL(gemm_kmajor_wide_h_kernel<true>, dim3((unsigned)units), dim3(512), wlds, s, w);
     else hipLaunchKernelGGL(gemm_kmajor_wide_h_kernel<false>, dim3((unsigned)units), dim3(512), wlds, s, w);
+    prof.done();
     TV_LAUNCH_CHECK("tv_gemm_f32(k-major wide)");
     hipLaunchKernelGGL(gemm_wide_tail_reduce_kernel, dim3((unsigned)(plan.w_tiles * 8)), dim3(256), 0, s, w);
     TV_LAUNCH_CHECK("tv_gemm_f32(k-major wide reduce)");
@@ -1866,6 +1904,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
     if (bm == 0) TV_GEMM(AM, 0, ACT); else if (bm == 1) TV_GEMM(AM, 1, ACT);                     \
     else if (bm == 2) TV_GEMM(AM, 2, ACT); else TV_GEMM(AM, 3, ACT);                             \
   } while (0)
+  ProfileScope prof(s, 0, m, n, k);
   if (act_operand == 1) {            // A row-major
     if (am == 0) TV_GEMM_B(0, 1); else TV_GEMM_B(1, 1);
   } else if (act_operand == 2) {     // B k-major
@@ -1875,6 +1914,7 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   }
 #undef TV_GEMM_B
 #undef TV_GEMM
+  prof.done();
   TV_LAUNCH_CHECK("tv_gemm_f32");
   if (g.splits > 1) {
     int64_t blocks = tv_cdiv(m * n, 256);
@@ -1892,6 +1932,34 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
 }  // namespace
 
 extern "C" int tv_gemm_f32_last_form(void) { return g_last_form; }
+
+extern "C" int tv_gemm_profile_begin(void) {
+  std::lock_guard<std::mutex> guard(g_profile.lock);
+  for (auto &r : g_profile.records) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  g_profile.records.clear();
+  g_profile.on = true;
+  return TV_OK;
+}
+
+extern "C" int64_t tv_gemm_profile_end(double *records, int64_t capacity) {
+  std::lock_guard<std::mutex> guard(g_profile.lock);
+  g_profile.on = false;
+  int64_t count = 0;
+  for (auto &r : g_profile.records) {
+    float ms = 0.f;
+    const bool ok = hipEventSynchronize(r.stop) == hipSuccess &&
+                    hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess;
+    if (ok && records && count < capacity) {
+      double *o = records + 5 * count;
+      o[0] = (double)ms; o[1] = (double)r.form; o[2] = (double)r.m; o[3] = (double)r.n; o[4] = (double)r.k;
+    }
+    if (ok) ++count;
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  g_profile.records.clear();
+  return count;
+}
 
 extern "C" int tv_gemm_f32(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k,
                            const float *a, int64_t lda, const float *b, int64_t ldb, float *c,
