@@ -79,7 +79,7 @@ def test_gemm_many_units_per_workgroup(device, m, n, k, ta, tb, strided):
     (1000, 1000, 51200, True, False),   # the weight gradient of the bench's layers
 ])
 def test_gemm_kmajor_operands_wide_form(device, m, n, k, act, strided):
-    """Weight gradients C = A^T B with both operands k-major go through gemm_kmajor_wide_kernel
+    """Weight gradients C = A^T B with both operands k-major go through gemm_kmajor_wide_h_kernel
     (planes k-major in LDS, transposing fragment reads, packed split-K slabs) when M, N are
     multiples of 4 and the tiles fit one round of the chip; against the float64 product."""
     from tracevae_amd import ops

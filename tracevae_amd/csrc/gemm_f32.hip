@@ -1024,10 +1024,10 @@ __device__ __forceinline__ void wide_split_store_h(const f32x4 &u, const f32x4 &
   asm volatile("ds_write_b128 %0, %1 offset:8192" ::"v"(addr), "v"(w1) : "memory");
 }
 
-// gemm_wide_kernel on fp16 planes: same tile (128 x 256), same eight multiplying waves, same
-// pipeline (B's images by LDS-DMA, A split by the multiplying waves between their matrix
+// The wide form (the bf16 kernel of round 2, removed, rebuilt on fp16 planes): 128 x 256 tile,
+// eight multiplying waves, the same pipeline (B's images by LDS-DMA, A split by the multiplying waves between their matrix
 // instructions, two LDS buffers, one raw barrier per k-tile, loads and DMAs counted by hand);
-// per wave and k-tile 24 matrix instructions and 16 ds_read_b128 (48 and 24 there), 4 DMAs (6).
+// per wave and k-tile 24 matrix instructions and 16 ds_read_b128 (48 and 24 on bf16 planes), 4 DMAs (6).
 // The buffers are 48 KB, so the output staging area (64 KB) lies behind them instead of inside
 // the buffer the last k-tile left free.
 template <bool ACT>
@@ -1299,8 +1299,8 @@ __device__ __forceinline__ void read_set_tr_h(const char *img, int xbase, int la
   }
 }
 
-// gemm_kmajor_wide_kernel on fp16 planes (the weight gradients): same units, same loads, same
-// pipeline; both operands are scaled by their own power of two as they are split.
+// The wide form for k-major operands (the weight gradients), likewise rebuilt on fp16 planes:
+// same units, same loads, same pipeline as its bf16 predecessor; both operands are scaled by their own power of two as they are split.
 template <bool ACT>
 __global__ __launch_bounds__(512) void gemm_kmajor_wide_h_kernel(GemmArgs g) {
   extern __shared__ __align__(16) char smem[];        // 2 x (A image | 2 B images), k-major
@@ -1536,11 +1536,11 @@ struct Plan {
   int64_t slab_bytes;                               // slabs of either split, at the workspace's start
   int64_t planes_bytes;                             // pre-split B behind them (0: split in the kernel)
   int64_t workspace_bytes;
-  // the wide form (128 x 256 tiles, gemm_wide_kernel): taken when the shape allows it and the
+  // the wide form (128 x 256 tiles, gemm_wide_h_kernel): taken when the shape allows it and the
   // operands qualify (run_gemm); its tail split has slabs of its own size
   bool wide;
   int64_t w_tiles, w_tail_first, w_tail_splits, w_tail_kchunk, w_slab_bytes;
-  // the wide form for k-major operands (gemm_kmajor_wide_kernel): every tile split over K into
+  // the wide form for k-major operands (gemm_kmajor_wide_h_kernel): every tile split over K into
   // one round of the chip; 0 splits = not taken
   int64_t km_splits, km_kchunk, km_slab_bytes;
   int64_t amax_bytes;                               // 2 x 256 partial maxima behind the planes
