@@ -423,9 +423,14 @@ int tv_affine_lrelu_bwd(int64_t rows, int64_t cols, const float *x, const float 
  * rows): the partial maxima of |out| for the product that reads `out` next (tv_gemm_f32_ex,
  * state 2), as tv_gat_aggregate_fwd leaves them.
  * ---------------------------------------------------------------------------------- */
+/* act_scale / act_shift (optional, cols floats each, same conditions as out_max): the rows of x
+ * go through lrelu(v * act_scale[col] + act_shift[col], act_slope) as they are gathered - the
+ * BatchNorm + LeakyReLU that ends the GAT layer in front of this one (gnn_layers.py:152-155) with
+ * its coefficients folded (tv_bn_finalize_coeffs), so that its output is never written. */
 int tv_graph_sum(int64_t rows_per_rep, int64_t n_rep, int64_t cols, const int64_t *indptr,
                  const int64_t *indices, const float *x, int scale_src, int scale_dst,
-                 float *out, float *out_max, void *stream);
+                 float *out, float *out_max, const float *act_scale, const float *act_shift,
+                 float act_slope, void *stream);
 /* deg^-1/2 per row of the (replicated) graph, for the GEMM row_scale epilogue */
 int tv_graph_norm(int64_t rows_per_rep, int64_t n_rep, const int64_t *indptr, float *norm,
                   void *stream);
@@ -433,8 +438,11 @@ int tv_graph_norm(int64_t rows_per_rep, int64_t n_rep, const int64_t *indptr, fl
 /* ------------------------------------------------------------------------------------
  * graph readout: dgl.nn.AvgPooling (model/pooling.py:45) = per-trace mean of node rows
  * ---------------------------------------------------------------------------------- */
+/* (act_scale / act_shift / act_slope: optional prologue on the rows, as in tv_graph_sum; needs
+ * cols % 4 == 0 and 16-byte aligned operands) */
 int tv_segment_mean_fwd(int64_t batch, int64_t cols, const int64_t *node_offsets,
-                        const float *x, float *out, void *stream);
+                        const float *x, float *out, const float *act_scale,
+                        const float *act_shift, float act_slope, void *stream);
 int tv_segment_mean_bwd(int64_t rows, int64_t cols, const int64_t *node_offsets,
                         const int64_t *graph_id, const float *dout, float *dx, void *stream);
 

@@ -526,9 +526,9 @@ def test_learning_rate_schedule_follows_the_finished_epoch_count(device):
 
 
 def test_deferred_batch_norm_equals_materialised(device, monkeypatch):
-    """Training step with BatchNorm + LeakyReLU applied inside the next layer's GEMMs
-    (`_DeferredBN`) against the same step with every activation materialised: loss, every
-    gradient, running statistics and batch counters."""
+    """Training step with BatchNorm + LeakyReLU applied inside the next layer's GEMMs and inside
+    the stacks' tail kernels (`_DeferredBN`) against the same step with every activation
+    materialised: loss, every gradient, running statistics and batch counters."""
     import tracevae_amd.model as model
     from tracevae_amd.batch import TraceGraphBatch
     V, M = 60, 16
@@ -541,6 +541,7 @@ def test_deferred_batch_norm_equals_materialised(device, monkeypatch):
     results = {}
     for fused in (True, False):
         monkeypatch.setattr(model, 'FUSED_BN_LINEAR', fused)
+        monkeypatch.setattr(model, 'DEFERRED_TAILS', fused)     # ... and inside the stacks' tails
         vae.load_state_dict(state)
         vae.zero_grad()
         G = TraceGraphBatch.from_store(store, np.arange(B), M)

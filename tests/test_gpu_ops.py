@@ -1169,6 +1169,54 @@ def test_bn_lrelu_linear_equals_composition(device, rows, cols, out, weighted):
         assert rel_err(res[0][i], res[1][i]) < 2e-5, name
 
 
+@pytest.mark.parametrize('kind,weighted', [('graph_sum', False), ('segment_mean', False),
+                                           ('segment_mean', True)])
+def test_bn_lrelu_tail_equals_composition(device, kind, weighted):
+    """A stack's tail with the BatchNorm + LeakyReLU of its last GAT layer applied inside the
+    tail's kernel (`bn_lrelu_graph_sum` / `bn_lrelu_segment_mean`) against bn_lrelu followed by
+    the plain tail: values, the three gradients and the running statistics."""
+    from tracevae_amd import ops
+    from tracevae_amd.batch import DeviceTraceStore, TraceGraphBatch
+    from helpers import make_flat
+    V, M, cols = 30, 24, 72
+    flat, lr = make_flat(40, V, M, seed=9)
+    store = DeviceTraceStore(flat, lr, V)
+    batch = TraceGraphBatch.from_store(store, np.arange(len(flat)), M).build_dgl()
+    g = batch.dec if kind == 'graph_sum' else batch.enc
+    rows = g.num_rows
+    gen = torch.Generator(device='cpu').manual_seed(rows)
+    x0 = (torch.randn(rows, cols, generator=gen) * 2 + 0.5).to(device)
+    g0 = (0.5 + torch.rand(cols, generator=gen)).to(device)
+    b0 = (0.2 * torch.randn(cols, generator=gen)).to(device)
+    rw = count = None
+    if weighted:
+        rw = torch.ones(rows, device=device)
+        rw[-20:] = torch.randint(1, 9, (20,), generator=gen).float().to(device)
+        count = int(rw.sum().item())
+    res = []
+    for fused in (True, False):
+        x, gm, bt = (t.clone().requires_grad_(True) for t in (x0, g0, b0))
+        rm, rv = torch.zeros(cols, device=device), torch.ones(cols, device=device)
+        if kind == 'graph_sum':
+            if fused:
+                out = ops.bn_lrelu_graph_sum(x, gm, bt, rm, rv, 1e-6, g, 0.1, 0.01, None, rw, count)
+                assert float(ops.operand_max(out).slots.max()) == float(out.detach().abs().max())
+            else:
+                out = ops.graph_sum(ops.bn_lrelu(x, gm, bt, rm, rv, True, 1e-6, 0.1, 0.01, None, rw, count), g)
+        else:
+            if fused:
+                out = ops.bn_lrelu_segment_mean(x, gm, bt, rm, rv, 1e-6, batch.node_offsets,
+                                                batch.graph_id, 0.1, 0.01, None, rw, count)
+            else:
+                out = ops.segment_mean(ops.bn_lrelu(x, gm, bt, rm, rv, True, 1e-6, 0.1, 0.01, None, rw, count),
+                                       batch.node_offsets, batch.graph_id)
+        dout = torch.randn(*out.shape, generator=torch.Generator().manual_seed(1)).to(device)
+        out.backward(dout)
+        res.append((out.detach(), x.grad, gm.grad, bt.grad, rm, rv))
+    for i, name in enumerate(('out', 'dx', 'dgamma', 'dbeta', 'running_mean', 'running_var')):
+        assert rel_err(res[0][i], res[1][i]) < 2e-5, name
+
+
 def test_gemm_operand_maxima_kept_by_the_caller(device):
     """`tv_gemm_f32_ex`: the maxima a first product leaves in the caller's buffer (state 1) give
     the later products of the same operand views (state 2) bit for bit what a scan of their own

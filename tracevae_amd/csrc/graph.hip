@@ -14,7 +14,8 @@ __device__ __forceinline__ float deg_norm(const int64_t *indptr, int64_t v) {
 __global__ __launch_bounds__(256) void graph_sum_vec_kernel(
     int64_t rows_per_rep, int64_t rows, int64_t c4, const int64_t *__restrict__ indptr,
     const int64_t *__restrict__ indices, const float *__restrict__ x, int scale_src,
-    int scale_dst, float *__restrict__ out, float *out_max) {
+    int scale_dst, float *__restrict__ out, float *out_max,
+    const float *__restrict__ act_scale, const float *__restrict__ act_shift, float act_slope) {
   const int lane = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * nw + (threadIdx.x >> 6);
@@ -28,6 +29,25 @@ __global__ __launch_bounds__(256) void graph_sum_vec_kernel(
       float4 acc[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // optional prologue: the rows are the pre-normalisation output of a GAT layer and go through
+      // lrelu(v * scale[col] + shift[col]) as they are gathered (the BatchNorm + LeakyReLU that
+      // the reference applies before this layer; its result is never written)
+      float4 psc[4], psh[4];
+      if (act_scale) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t q = q0 + lane + 64 * c;
+          psc[c] = (q < c4) ? reinterpret_cast<const float4 *>(act_scale)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          psh[c] = (q < c4) ? reinterpret_cast<const float4 *>(act_shift)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      auto act = [&](float4 v, int c) -> float4 {
+        if (!act_scale) return v;
+        return make_float4(tv_lrelu(fmaf(v.x, psc[c].x, psh[c].x), act_slope),
+                           tv_lrelu(fmaf(v.y, psc[c].y, psh[c].y), act_slope),
+                           tv_lrelu(fmaf(v.z, psc[c].z, psh[c].z), act_slope),
+                           tv_lrelu(fmaf(v.w, psc[c].w, psh[c].w), act_slope));
+      };
       // two neighbour rows in flight per trip (the rows are still added in edge order)
       int64_t p = p0;
       for (; p + 2 <= p1; p += 2) {
@@ -45,6 +65,11 @@ __global__ __launch_bounds__(256) void graph_sum_vec_kernel(
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+          t0[c] = act(t0[c], c);
+          t1[c] = act(t1[c], c);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
           // DGL scales the source features first, then sums (appendix A2)
           acc[c].x += t0[c].x * ns0; acc[c].y += t0[c].y * ns0; acc[c].z += t0[c].z * ns0; acc[c].w += t0[c].w * ns0;
           acc[c].x += t1[c].x * ns1; acc[c].y += t1[c].y * ns1; acc[c].z += t1[c].z * ns1; acc[c].w += t1[c].w * ns1;
@@ -58,7 +83,7 @@ __global__ __launch_bounds__(256) void graph_sum_vec_kernel(
         for (int c = 0; c < 4; ++c) {
           const int64_t q = q0 + lane + 64 * c;
           if (q < c4) {
-            const float4 t = urow[q];
+            const float4 t = act(urow[q], c);
             acc[c].x += t.x * ns; acc[c].y += t.y * ns; acc[c].z += t.z * ns; acc[c].w += t.w * ns;
           }
         }
@@ -128,25 +153,40 @@ __global__ __launch_bounds__(256) void segment_mean_fwd_kernel(int64_t C,
 __global__ __launch_bounds__(256) void segment_mean_fwd_vec_kernel(int64_t C,
                                                                    const int64_t *__restrict__ off,
                                                                    const float *__restrict__ x,
-                                                                   float *__restrict__ out) {
+                                                                   float *__restrict__ out,
+                                                                   const float *__restrict__ act_scale,
+                                                                   const float *__restrict__ act_shift,
+                                                                   float act_slope) {
   const int64_t b = blockIdx.x, c4 = C >> 2;
   const int64_t q = (int64_t)blockIdx.y * 256 + threadIdx.x;
   if (q >= c4) return;
   const int64_t r0 = off[b], r1 = off[b + 1];
   const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  // optional prologue lrelu(v * scale[col] + shift[col]) on the rows as they are read (see
+  // graph_sum_vec_kernel)
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (act_scale) {
+    sc = reinterpret_cast<const float4 *>(act_scale)[q];
+    sh = reinterpret_cast<const float4 *>(act_shift)[q];
+  }
+  auto act = [&](float4 v) -> float4 {
+    if (!act_scale) return v;
+    return make_float4(tv_lrelu(fmaf(v.x, sc.x, sh.x), act_slope), tv_lrelu(fmaf(v.y, sc.y, sh.y), act_slope),
+                       tv_lrelu(fmaf(v.z, sc.z, sh.z), act_slope), tv_lrelu(fmaf(v.w, sc.w, sh.w), act_slope));
+  };
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t r = r0;
   for (; r + 4 <= r1; r += 4) {
     float4 v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = x4[(r + j) * c4 + q];
+    for (int j = 0; j < 4; ++j) v[j] = act(x4[(r + j) * c4 + q]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
     }
   }
   for (; r < r1; ++r) {
-    const float4 v = x4[r * c4 + q];
+    const float4 v = act(x4[r * c4 + q]);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
   const float n = (float)(r1 - r0);
@@ -319,6 +359,7 @@ inline unsigned ew_blocks(int64_t work_items) {
 extern "C" int tv_graph_sum(int64_t rows_per_rep, int64_t n_rep, int64_t cols,
                             const int64_t *indptr, const int64_t *indices, const float *x,
                             int scale_src, int scale_dst, float *out, float *out_max,
+                            const float *act_scale, const float *act_shift, float act_slope,
                             void *stream) {
   TV_REQUIRE(rows_per_rep >= 0 && n_rep >= 1 && cols >= 1, "tv_graph_sum: bad sizes");
   const int64_t rows = rows_per_rep * n_rep;
@@ -328,12 +369,16 @@ extern "C" int tv_graph_sum(int64_t rows_per_rep, int64_t n_rep, int64_t cols,
   hipStream_t s = (hipStream_t)stream;
   const bool vec = cols % 4 == 0 && cols >= 64 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0);
   TV_REQUIRE(!out_max || vec, "tv_graph_sum: out_max needs rows of a multiple of 4 floats (>= 64), 16-byte aligned");
+  TV_REQUIRE((act_scale == nullptr) == (act_shift == nullptr), "tv_graph_sum: act_scale and act_shift go together");
+  TV_REQUIRE(!act_scale || (vec && ((((uintptr_t)act_scale | (uintptr_t)act_shift) & 15) == 0)),
+             "tv_graph_sum: the prologue needs rows of a multiple of 4 floats (>= 64) and 16-byte aligned operands");
   if (vec) {
     int64_t blocks = tv_cdiv(rows, 4);
     if (blocks > 8192) blocks = 8192;
     if (out_max) TV_HIP(hipMemsetAsync(out_max, 0, 256 * sizeof(float), s));
     hipLaunchKernelGGL(graph_sum_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rows_per_rep,
-                       rows, cols / 4, indptr, indices, x, scale_src, scale_dst, out, out_max);
+                       rows, cols / 4, indptr, indices, x, scale_src, scale_dst, out, out_max, act_scale,
+                       act_shift, act_slope);
   } else {
     hipLaunchKernelGGL(graph_sum_scalar_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, s,
                        rows_per_rep, rows, cols, indptr, indices, x, scale_src, scale_dst, out);
@@ -355,14 +400,20 @@ extern "C" int tv_graph_norm(int64_t rows_per_rep, int64_t n_rep, const int64_t 
 }
 
 extern "C" int tv_segment_mean_fwd(int64_t batch, int64_t cols, const int64_t *node_offsets,
-                                   const float *x, float *out, void *stream) {
+                                   const float *x, float *out, const float *act_scale,
+                                   const float *act_shift, float act_slope, void *stream) {
   TV_REQUIRE(batch >= 0 && cols >= 1, "tv_segment_mean_fwd: bad sizes");
   if (batch == 0) return TV_OK;
   TV_REQUIRE(node_offsets && x && out, "tv_segment_mean_fwd: null pointer");
-  if (cols % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+  const bool vec = cols % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+  TV_REQUIRE((act_scale == nullptr) == (act_shift == nullptr),
+             "tv_segment_mean_fwd: act_scale and act_shift go together");
+  TV_REQUIRE(!act_scale || (vec && ((((uintptr_t)act_scale | (uintptr_t)act_shift) & 15) == 0)),
+             "tv_segment_mean_fwd: the prologue needs rows of a multiple of 4 floats and 16-byte aligned operands");
+  if (vec) {
     const dim3 grid((unsigned)batch, (unsigned)tv_cdiv(cols / 4, 256));
     hipLaunchKernelGGL(segment_mean_fwd_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, cols,
-                       node_offsets, x, out);
+                       node_offsets, x, out, act_scale, act_shift, act_slope);
   } else {
     const dim3 grid((unsigned)batch, (unsigned)tv_cdiv(cols, 256));
     hipLaunchKernelGGL(segment_mean_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, cols,

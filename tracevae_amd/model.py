@@ -51,6 +51,8 @@ FUSED_BN_LINEAR = True
 # this constant; a kernel-timing run, `ops.TIMER.enabled`, takes the operator-level calls, whose
 # HIP events bracket single kernels)
 FUSED_GAT_LAYER = True
+# the BatchNorm + LeakyReLU that ends a stack applied inside the stack's tail kernel
+DEFERRED_TAILS = True
 
 
 # ---------------------------------------------------------------------------------------
@@ -231,6 +233,25 @@ class _DeferredBN(object):
                                    bn.running_var, bn.eps, bn.momentum, LRELU_SLOPE, self.stats,
                                    self.row_weight, self.count, attn_l, attn_r)
 
+    # the stack's tail applies it as it reads the rows (`ops._BNLReLUTail`)
+    def graph_sum(self, graph):
+        bn = self.bn
+        bn.count_batch()
+        return ops.bn_lrelu_graph_sum(self.x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      bn.eps, graph, bn.momentum, LRELU_SLOPE, self.stats,
+                                      self.row_weight, self.count)
+
+    def segment_mean(self, node_offsets, graph_id):
+        bn = self.bn
+        bn.count_batch()
+        return ops.bn_lrelu_segment_mean(self.x, bn.weight, bn.bias, bn.running_mean,
+                                         bn.running_var, bn.eps, node_offsets, graph_id,
+                                         bn.momentum, LRELU_SLOPE, self.stats, self.row_weight,
+                                         self.count)
+
+    def materialise(self):
+        return self.bn.forward_lrelu(self.x, self.stats, self.row_weight, self.count)
+
 
 class GATConvAgg(nn.Module):
     """GATConv -> concat heads -> BatchNorm -> LeakyReLU (gnn_layers.py:112-157)."""
@@ -304,8 +325,17 @@ class GraphConv(nn.Module):
         self.input_dim, self.output_dim = input_dim, output_dim
         self.gnn = _GraphConvParams(input_dim, output_dim)
 
-    def forward(self, graph: ops.DeviceGraph, h: torch.Tensor, n_rep: int = 1) -> torch.Tensor:
+    def takes_deferred(self) -> bool:
+        # (the float4 form of the aggregation kernel: rows of a multiple of 4, at least 64, floats)
+        return (self.input_dim <= self.output_dim and self.input_dim % 4 == 0
+                and self.input_dim >= 64)
+
+    def forward(self, graph: ops.DeviceGraph, h, n_rep: int = 1) -> torch.Tensor:
         w, b = self.gnn.weight, self.gnn.bias
+        if isinstance(h, _DeferredBN):
+            if self.takes_deferred() and n_rep == 1:
+                return ops.matmul_nn(h.graph_sum(graph), w, b)
+            h = h.materialise()
         if self.input_dim > self.output_dim:
             # DGL multiplies by W first when in > out (appendix A2)
             if self.output_dim <= 8:
@@ -320,7 +350,11 @@ class GraphConv(nn.Module):
 class _Pooling(nn.Module):
     """dgl.nn.AvgPooling (pooling.py:45): no parameters."""
 
-    def forward(self, batch: DeviceBatch, h: torch.Tensor) -> torch.Tensor:
+    def forward(self, batch: DeviceBatch, h) -> torch.Tensor:
+        if isinstance(h, _DeferredBN):
+            if h.x.shape[1] % 4 == 0:
+                return h.segment_mean(batch.node_offsets, batch.graph_id)
+            h = h.materialise()
         return ops.segment_mean(h, batch.node_offsets, batch.graph_id)
 
 
@@ -333,9 +367,13 @@ class GNNSequential(nn.Module):
 
     def _run(self, graph, h, n_rep, tail_arg, row_weight, count):
         layers = list(self.gnn)[:-1]
-        for i, layer in enumerate(layers):
-            h = layer(graph, h, n_rep, row_weight, count, defer=i + 1 < len(layers))
         tail = self.gnn[len(self.gnn) - 1]
+        # the last layer's BatchNorm + LeakyReLU rides in the tail's kernel where the tail reads
+        # wide rows (AvgPooling; GraphConv that aggregates before it multiplies)
+        tail_defers = DEFERRED_TAILS and n_rep == 1 and (
+            isinstance(tail, _Pooling) or (isinstance(tail, GraphConv) and tail.takes_deferred()))
+        for i, layer in enumerate(layers):
+            h = layer(graph, h, n_rep, row_weight, count, defer=i + 1 < len(layers) or tail_defers)
         if isinstance(tail, _Pooling):
             return tail(tail_arg, h)
         return tail(graph, h, n_rep)

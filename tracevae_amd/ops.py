@@ -919,7 +919,7 @@ class _GraphSum(Function):
         box = OperandMax(x.device) if (cols % 4 == 0 and cols >= 64) else None
         hip.call('tv_graph_sum', graph.num_rows, n_rep, cols, hip.ptr(graph.indptr),
                  hip.ptr(graph.indices), hip.ptr(x), int(scale_src), int(scale_dst), hip.ptr(out),
-                 None if box is None else box.slots.data_ptr())
+                 None if box is None else box.slots.data_ptr(), None, None, 0.0)
         if box is not None:
             _LAST_OUT_MAX['graph_sum'] = box
         ctx.graph, ctx.n_rep, ctx.flags = graph, n_rep, (scale_src, scale_dst)
@@ -934,7 +934,7 @@ class _GraphSum(Function):
         dx = torch.empty_like(dout)
         hip.call('tv_graph_sum', g.num_rows, ctx.n_rep, dout.shape[1], hip.ptr(g.indptr),
                  hip.ptr(g.indices), hip.ptr(dout), int(ctx.flags[1]), int(ctx.flags[0]),
-                 hip.ptr(dx), None)
+                 hip.ptr(dx), None, None, None, 0.0)
         return dx, None, None, None, None
 
 
@@ -953,7 +953,7 @@ class _SegmentMean(Function):
         batch = node_offsets.shape[0] - 1
         out = torch.empty([batch, x.shape[1]], dtype=_f32, device=x.device)
         hip.call('tv_segment_mean_fwd', batch, x.shape[1], hip.ptr(node_offsets), hip.ptr(x),
-                 hip.ptr(out))
+                 hip.ptr(out), None, None, 0.0)
         ctx.save_for_backward(node_offsets, graph_id)
         ctx.rows = x.shape[0]
         return out
@@ -971,6 +971,105 @@ class _SegmentMean(Function):
 
 def segment_mean(x, node_offsets, graph_id):
     return _SegmentMean.apply(x, node_offsets, graph_id)
+
+
+class _BNLReLUTail(Function):
+    """`graph_sum(LeakyReLU(BatchNorm_train(x)))` or `segment_mean(...)` without writing the
+    activation: the last GAT layer of a stack hands its pre-normalisation output to the stack's
+    tail (GraphConv aggregation / AvgPooling), whose kernel applies the folded BatchNorm +
+    LeakyReLU to the rows as it reads them.  Same function as `_BNLReLUTrain` followed by
+    `_GraphSum` / `_SegmentMean`; the backward pass is the tail's own followed by
+    `tv_bn_lrelu_bwd` on the gradient of the (never materialised) activation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope, stats,
+                row_weight, count, kind, graph, node_offsets, graph_id):
+        x = _check(x, 'x')
+        gamma, beta = _check(gamma, 'gamma'), _check(beta, 'beta')
+        rows, cols = x.shape
+        dev = x.device
+        if cols % 4:
+            raise ValueError('the deferred BatchNorm tail needs a multiple of 4 columns')
+        count = rows if row_weight is None else int(count)
+        if count < 2:
+            raise ValueError('Expected more than 1 value per channel when training')
+        if stats is None or stats.numel() == 0:
+            stats = torch.empty([hip.query('tv_stat_blocks', rows), 2, cols], dtype=_f32, device=dev)
+            hip.call('tv_colstats', rows, cols, hip.ptr(x), hip.ptr(row_weight), hip.ptr(stats))
+        coeffs = torch.empty([4, cols], dtype=_f32, device=dev)
+        mean, rstd, scale, shift = (coeffs[i] for i in range(4))
+        hip.call('tv_bn_finalize_coeffs', cols, stats.shape[0], hip.ptr(stats), count, float(eps),
+                 float(momentum), hip.ptr(mean), hip.ptr(rstd), hip.ptr(running_mean),
+                 hip.ptr(running_var), hip.ptr(gamma), hip.ptr(beta), hip.ptr(scale),
+                 hip.ptr(shift), None)
+        box = None
+        if kind == 'graph_sum':
+            if rows != graph.num_rows:
+                raise ValueError(f'graph_sum: {rows} rows do not match graph {graph.num_rows}')
+            out = torch.empty_like(x)
+            box = OperandMax(dev) if cols >= 64 else None
+            hip.call('tv_graph_sum', graph.num_rows, 1, cols, hip.ptr(graph.indptr),
+                     hip.ptr(graph.indices), hip.ptr(x), 1, 1, hip.ptr(out),
+                     None if box is None else box.slots.data_ptr(), hip.ptr(scale), hip.ptr(shift),
+                     float(slope))
+            if box is not None:
+                _LAST_OUT_MAX['graph_sum'] = box
+        else:
+            batch = node_offsets.shape[0] - 1
+            out = torch.empty([batch, cols], dtype=_f32, device=dev)
+            hip.call('tv_segment_mean_fwd', batch, cols, hip.ptr(node_offsets), hip.ptr(x),
+                     hip.ptr(out), hip.ptr(scale), hip.ptr(shift), float(slope))
+        ctx.save_for_backward(x, coeffs, gamma, beta, *(() if kind == 'graph_sum'
+                                                       else (node_offsets, graph_id)))
+        ctx.kind, ctx.graph = kind, graph
+        ctx.slope = float(slope)
+        ctx.row_weight, ctx.count = row_weight, count
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, coeffs, gamma, beta = ctx.saved_tensors[:4]
+        mean, rstd = coeffs[0], coeffs[1]
+        rows, cols = x.shape
+        dout = _check(dout, 'dout')
+        dact = torch.empty_like(x)
+        if ctx.kind == 'graph_sum':
+            g = ctx.graph          # symmetric graph: the transpose aggregation is the same kernel
+            hip.call('tv_graph_sum', g.num_rows, 1, cols, hip.ptr(g.indptr), hip.ptr(g.indices),
+                     hip.ptr(dout), 1, 1, hip.ptr(dact), None, None, None, 0.0)
+        else:
+            node_offsets, graph_id = ctx.saved_tensors[4:]
+            hip.call('tv_segment_mean_bwd', rows, cols, hip.ptr(node_offsets), hip.ptr(graph_id),
+                     hip.ptr(dout), hip.ptr(dact))
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        wsb = hip.query('tv_bn_lrelu_bwd_workspace_bytes', rows, cols)
+        ws = _workspace(wsb, x.device)
+        hip.call('tv_bn_lrelu_bwd', rows, cols, hip.ptr(x), hip.ptr(dact), hip.ptr(mean),
+                 hip.ptr(rstd), hip.ptr(gamma), hip.ptr(beta), ctx.slope, hip.ptr(ctx.row_weight),
+                 ctx.count, hip.ptr(dx), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), wsb)
+        return (dx, dgamma, dbeta) + (None,) * 12
+
+
+def bn_lrelu_graph_sum(x, gamma, beta, running_mean, running_var, eps: float, graph: DeviceGraph,
+                       momentum: float = 0.1, slope: float = 0.01, stats=None, row_weight=None,
+                       count=None):
+    """`graph_sum(bn_lrelu(x, training=True), graph)` as one operator (see `_BNLReLUTail`)."""
+    out = _BNLReLUTail.apply(x, gamma, beta, running_mean, running_var, eps, momentum, slope,
+                             stats, row_weight, count, 'graph_sum', graph, None, None)
+    box = _LAST_OUT_MAX.pop('graph_sum', None)
+    if box is not None:
+        box.attach(out)
+    return out
+
+
+def bn_lrelu_segment_mean(x, gamma, beta, running_mean, running_var, eps: float, node_offsets,
+                          graph_id, momentum: float = 0.1, slope: float = 0.01, stats=None,
+                          row_weight=None, count=None):
+    """`segment_mean(bn_lrelu(x, training=True), ...)` as one operator (see `_BNLReLUTail`)."""
+    return _BNLReLUTail.apply(x, gamma, beta, running_mean, running_var, eps, momentum, slope,
+                              stats, row_weight, count, 'segment_mean', None, node_offsets, graph_id)
 
 
 class _Embedding(Function):
