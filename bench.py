@@ -386,6 +386,13 @@ def main():
     train_gemm_tags = ops.TIMER.by_tag('gemm_f32')
     train_mp_tags = {n: ops.TIMER.by_tag(n) for n in ('gat_aggregate_fwd', 'gat_aggregate_bwd')}
     if args.gemm_shapes and rank == 0:
+        agg = {}
+        for ms, form, m, n, k in train_gemm_kernels:
+            rec = agg.setdefault((int(form), int(m), int(n), int(k)), [0, 0.0])
+            rec[0] += 1; rec[1] += ms
+        for (form, m, n, k), (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+            print(f'kernel alone form={form} m={m:7d} n={n:5d} k={k:7d} x{cnt / args.steps:5.1f}/step '
+                  f'{ms / cnt * 1e3:8.1f} us  {2.0 * m * n * k * cnt / ms / 1e9:6.1f} TF', file=sys.stderr)
         rows = sorted(ops.TIMER.by_tag('gemm_f32').items(), key=lambda kv: -kv[1][2])
         for (m, n, k, ta, tb, form), (cnt, work, ms) in rows:
             print(f'gemm m={m:7d} n={n:5d} k={k:7d} ta={int(ta)} tb={int(tb)} form={form}  x{cnt / args.steps:5.1f}/step '

@@ -1332,8 +1332,11 @@ __global__ __launch_bounds__(512) void gemm_kmajor_wide_h_kernel(GemmArgs g) {
     off[j] = j < 2 ? (unsigned)((krow(j) * g.lda + axc) * 4) : (unsigned)((krow(j) * g.ldb + bxc) * 4);
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
   if constexpr (ACT) {
-    sc = *reinterpret_cast<const f32x4 *>(g.act_scale + n0 + bxc);
-    sh = *reinterpret_cast<const f32x4 *>(g.act_shift + n0 + bxc);
+    // (the operand's power-of-two scale rides in the coefficients: lrelu is positively
+    // homogeneous and a power of two commutes with every rounding, so lrelu(v sc + sh) sb =
+    // lrelu(v (sc sb) + sh sb) bit for bit - one multiplication less per element and k-tile)
+    sc = *reinterpret_cast<const f32x4 *>(g.act_scale + n0 + bxc) * sb;
+    sh = *reinterpret_cast<const f32x4 *>(g.act_shift + n0 + bxc) * sb;
   }
   f32x4 r[6];
   auto tile_a = [&](int kt) { return a_base + (int64_t)kt * BK * g.lda * 4; };
@@ -1350,8 +1353,9 @@ __global__ __launch_bounds__(512) void gemm_kmajor_wide_h_kernel(GemmArgs g) {
           const float a = v[e] * sc[e] + sh[e];
           v[e] = fmaxf(a, a * g.act_slope);
         }
+      } else {
+        v *= sb;
       }
-      v *= sb;
       kmajor_split_store_h(v, buf + H_OPERAND_BYTES + (bx >> 7) * H_OPERAND_BYTES +
                                   kmajor_offset(krow(j), (bx & 127) >> 3) + 2 * (bx & 7));
     }
