@@ -1050,7 +1050,19 @@ __global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
           for (int c = 0; c < CH; ++c) {
             const int q = lane + 64 * c;
             x[u][c] = (q < c4) ? frow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-            y[u][c] = (q < c4) ? wrow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          // the self-loop: dout[u] is already here (every row has one, a padded decoder slot
+          // nothing else; the kernel is bound by the read requests a CU keeps in flight, §4f, and
+          // this row is one in 1 + 2 deg of them)
+          if (sj == r) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) y[u][c] = d[c];
+          } else {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              const int q = lane + 64 * c;
+              y[u][c] = (q < c4) ? wrow[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
           }
         }
         float part[U][HT];
