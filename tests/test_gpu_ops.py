@@ -1269,6 +1269,7 @@ def test_gat_forward_windowed_equals_per_row(device, n_rep, epilogue, monkeypatc
         nbrs[r].append(r + 37)
     nbrs[7] = [7] + list(range(100, 180))                 # more than 64 in-neighbours
     nbrs[33] = []                                         # no in-edge at all
+    nbrs[R - 1] = []                                      # ... and the last row (indptr = E)
     indptr = np.zeros(R + 1, np.int64)
     indptr[1:] = np.cumsum([len(x) for x in nbrs])
     indices = np.concatenate([np.asarray(x, np.int64) for x in nbrs if len(x)])

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * LDS_WAVES, 4) void gat_aggregate_fwd_lds_kerne
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int lim = wi + wstep < wend ? deg_1[j] : 0;
-        s_1[j] = (int)a.indices[p0_1[j] + (lane < lim ? lane : 0)];
+        s_1[j] = (lane < lim) ? (int)a.indices[p0_1[j] + lane] : 0;
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) load_pd(w2, j, p0_2[j], deg_2[j]);
