@@ -1359,7 +1359,7 @@ def test_operand_maxima_from_the_producing_kernels(device):
         assert ops.operand_max(out) is None
     # GraphConv: the aggregated rows carry their maxima into the product that follows, which keeps
     # the maxima of x, of the weights and of the output gradient between its three products
-    wn = (0.05 * rnd(H * F, 52)).requires_grad_(True)          # [in, out], odd class count padded
+    wn = (0.05 * rnd(H * F, 101)).requires_grad_(True)         # [in, out], an odd class count
     hsrc = rnd(g.num_rows, H * F).requires_grad_(True)
     agg = ops.graph_sum(hsrc, g)
     box = ops.operand_max(agg)

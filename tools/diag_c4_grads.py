@@ -13,6 +13,7 @@ dev = torch.device('cuda:0')
 argv = sys.argv[1:]
 V, M, WIDTH, LAYERS, batch, ZD = (int(x) for x in argv[:6]) if len(argv) >= 6 else (10001, 500, 1000, 4, 5, 20)
 EXTRA = LONG_TRACE_FLAGS if V > 5000 else ()
+WIDTH, LAYERS = WIDTH or None, LAYERS or None      # 0 0 = the default widths (configs[1])
 watch = argv[6:] or ['struct_vae.pG_node_type_logits.gnn.3.gnn.attn_r', 'struct_vae.pG_node_type_logits.gnn.0.gnn.attn_l',
          'latency_vae.pG_node_features.gnn.2.gnn.fc.weight', 'latency_vae.pG_node_features.gnn.2.normalization.bias',
          'struct_vae.pG_node_type_logits.gnn.1.gnn.fc.weight', 'latency_vae.pG_node_features.gnn.3.gnn.fc.weight',

@@ -1774,8 +1774,12 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   // zero there anyway; not with a prologue, whose coefficient vectors end at K)
   const bool a_rows16 = g.a_vec || (!trans_a && act_operand == 0 && lda % 4 == 0 &&
                                     (((uintptr_t)a & 15) == 0) && lda >= ((k + 3) & ~3ll));
+  // (not for the 40 / 50-wide first layers: with n or k below 64 the product is bound by the
+  // bytes of its tall operand or of its output, and the producer / consumer form, whose stores
+  // overlap the next unit, streams them faster - 51200 x 40 x 1004: 123 -> 90 us, 51200 x 1004 x
+  // 40: 79 -> 70 us, tools/narrow_gemm_lab.py)
   const bool take_wide = plan.wide && presplit && !trans_a && a_rows16 && !row_scale && !accumulate &&
-                         act_operand != 2;
+                         act_operand != 2 && k >= 64 && n >= 64;
   if (presplit) {
     TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gemm_f32: workspace must be 16-byte aligned");
     char *planes = (char *)workspace + plan.slab_bytes;
