@@ -170,6 +170,20 @@ int tv_sampled_graph_fill(int64_t graphs, int64_t max_node_count, int64_t num_ed
  * ---------------------------------------------------------------------------------- */
 int64_t tv_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k);
 int tv_gemm_f32_last_form(void);
+/* B split ahead of its products, several operands per launch (no counterpart in the reference:
+ * its GEMMs are torch's).  tv_gemm_b_form: the form of B's plane image in a plain product
+ * C[m,n] = A[m,k] . op(B) with a row-major, 16-byte readable A - -1: B is split inside the
+ * kernel (not preparable), 0: three bf16 planes, 1: two fp16 planes behind the operand's
+ * power-of-two scale.  tv_gemm_prepared_b_bytes: size of that image.  tv_gemm_prepare_b_batch:
+ * writes the images of `count` (<= 32) operands in one launch; the arrays are HOST arrays of
+ * `count` entries (m / n / k / trans_b / b / ldb of each product, b_max = the operand's
+ * TV_GEMM_MAX_SLOTS partial maxima on the device - needed for form 1 -, planes = where its image
+ * goes, 16-byte aligned).  The images are then passed as `b` with b_max_state 3 / 4. */
+int tv_gemm_b_form(int64_t m, int64_t n, int64_t k);
+int64_t tv_gemm_prepared_b_bytes(int64_t m, int64_t n, int64_t k);
+int tv_gemm_prepare_b_batch(int64_t count, const int64_t *m, const int64_t *n, const int64_t *k,
+                            const int *trans_b, const float *const *b, const int64_t *ldb,
+                            const float *const *b_max, void *const *planes, void *stream);
 /* Measurement aid, no counterpart in the reference.  Between _begin and _end the MAIN kernel of
  * every product (not the operand scans, the split of B or the reductions around it) is bracketed
  * by a pair of HIP events on the stream it is launched on.  _end waits for them, writes
@@ -207,6 +221,10 @@ int tv_gemm_f32_act(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, c
  * if this product needs it; 2: the buffer holds the maxima of exactly this operand view (same
  * rows, columns and prologue coefficients) - the library does not look at the operand again.
  * Whether a state-1 buffer was filled: tv_gemm_f32_last_form() != 0 after the call.
+ * For B two more states: 3 / 4 = `b` is not the operand but its plane image, written ahead of
+ * the product by tv_gemm_prepare_b_batch in the bf16 (3) / fp16 (4) form, and b_max (state 4)
+ * holds the maxima the image was scaled by; ldb is then only checked against n / k.  The form
+ * must be the one this product takes (tv_gemm_b_form), else the call fails.
  * No counterpart in the reference (its GEMMs are torch's); the shapes are those of
  * tv_gemm_f32_act. */
 int tv_gemm_f32_ex(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const float *a,
@@ -287,6 +305,13 @@ int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_feats, const
                            float *weight_ext_max, /* nullable: TV_GEMM_MAX_SLOTS partial maxima of
                                                      |weight_ext|, for tv_gemm_f32_ex state 2 */
                            void *stream);
+/* the same for up to 16 layers in one launch (HOST arrays of `count` entries; every layer's
+ * ceil(in_feats / 16) * heads must be <= 256: its maxima go to one slot per workgroup) */
+int tv_gat_fc_score_weight_batch(int64_t count, const int64_t *heads, const int64_t *feats,
+                                 const int64_t *in_feats, const float *const *weight,
+                                 const float *const *attn_l, const float *const *attn_r,
+                                 float *const *weight_ext, float *const *weight_ext_max,
+                                 void *stream);
 int tv_gat_fc_score_weight_bwd(int64_t heads, int64_t feats, int64_t in_feats,
                                const float *weight, const float *attn_l, const float *attn_r,
                                float *dweight_ext, float *dattn_l, float *dattn_r, void *stream);
@@ -334,6 +359,13 @@ int tv_gat_aggregate_bwd(int64_t rows_per_rep, int64_t n_rep, int64_t heads, int
  *   dweight_ext [H*F + pad4(2H), in_feats]: rows 0..H*F-1 are dW on return.  dx [rows, in_feats];
  *   dgamma / dbeta [in_feats] with a deferred input.  need_dx / need_dw: skip the products whose
  *   results nobody reads.  Workspace: tv_gat_layer_workspace_bytes(...) bytes, 256-byte aligned.
+ * Prepared weights: the weights of a stack change once per step, so a host may build every
+ * layer's extended weight and its plane images - forward orientation for the fc product,
+ * transposed for the input gradient - with ONE tv_gat_fc_score_weight_batch and ONE
+ * tv_gemm_prepare_b_batch call per stack instead of three launches per layer.  Then
+ * `weight_ext` is that image and w_prepared (forward) / w_max_state (backward) is 3 or 4, the
+ * form tv_gemm_b_form reports for the product (tv_gemm_f32_ex states of B); w_max holds the
+ * maxima tv_gat_fc_score_weight_batch left.  0 / 1 / 2: the layer builds them itself, as before.
  * ---------------------------------------------------------------------------------- */
 int64_t tv_gat_layer_workspace_bytes(int64_t rows, int64_t in_feats, int64_t heads,
                                      int64_t feats, int64_t num_edges);
@@ -346,7 +378,7 @@ int tv_gat_layer_train_fwd(int64_t rows, int64_t in_feats, int64_t heads, int64_
                            const float *attn_l, const float *attn_r, const float *bias,
                            const float *stats_row_weight, float *weight_ext, float *ft,
                            float *out, float *alpha, float *out_stats, float *x_max,
-                           int x_max_state, float *w_max, void *workspace,
+                           int x_max_state, float *w_max, int w_prepared, void *workspace,
                            int64_t workspace_bytes, void *stream);
 int tv_gat_layer_train_bwd(int64_t rows, int64_t in_feats, int64_t heads, int64_t feats,
                            int64_t num_edges, const int64_t *indptr, const int64_t *indices,

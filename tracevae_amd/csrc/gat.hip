@@ -1307,17 +1307,17 @@ int check_strides(const char *name, int64_t heads, int64_t feats, const float *f
 // row segments; with 64 columns per workgroup a 1000-wide layer filled 32 of the 256 CUs and the
 // launch took 13 us of every layer's forward pass).
 constexpr int SW_COLS = 16, SW_GROUPS = 64;
-__global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F, int64_t K,
-                                                                   const float *__restrict__ W,
-                                                                   const float *__restrict__ al,
-                                                                   const float *__restrict__ ar,
-                                                                   float *__restrict__ Wx,
-                                                                   float *__restrict__ w_max) {
+__device__ __forceinline__ void gat_fc_score_weight_block(int bx, int by, int gx, int gy, int H, int F,
+                                                          int64_t K, const float *__restrict__ W,
+                                                          const float *__restrict__ al,
+                                                          const float *__restrict__ ar,
+                                                          float *__restrict__ Wx,
+                                                          float *__restrict__ w_max) {
   __shared__ float part[2][SW_GROUPS][SW_COLS];
   float wmx = 0.f;                                 // max |entry| of what this thread writes
   const int kx = threadIdx.x % SW_COLS, fg = threadIdx.x / SW_COLS;
-  const int h = blockIdx.y;
-  const int64_t k = (int64_t)blockIdx.x * SW_COLS + kx;
+  const int h = by;
+  const int64_t k = (int64_t)bx * SW_COLS + kx;
   float sl = 0.f, sr = 0.f;
   if (k < K) {
     // eight rows in flight per thread: the kernel is bound by the latency of its loads
@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
   if (w_max) {                                     // for the fp16 GEMM forms (tv_gemm_f32_ex, state 2)
     __shared__ float wave_max[16];
     wmx = tv_wave_max(wmx);
-    const int nblocks = (int)(gridDim.x * gridDim.y), block = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+    const int nblocks = gx * gy, block = bx + gx * by;
     if (nblocks <= 256) {
       // a slot per workgroup, the rest zeroed here: plain stores, nothing to clear beforehand
       if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = wmx;
@@ -1375,6 +1375,31 @@ __global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F,
   // rows that pad 2H up to a multiple of 4 (rows of [ft | el | er] stay 16-byte aligned)
   const int pad = ((2 * H + 3) & ~3) - 2 * H;
   if (h == 0 && fg >= 2 && fg < 2 + pad && k < K) Wx[((int64_t)H * F + 2 * H + (fg - 2)) * K + k] = 0.f;
+}
+__global__ __launch_bounds__(1024) void gat_fc_score_weight_kernel(int H, int F, int64_t K,
+                                                                   const float *__restrict__ W,
+                                                                   const float *__restrict__ al,
+                                                                   const float *__restrict__ ar,
+                                                                   float *__restrict__ Wx,
+                                                                   float *__restrict__ w_max) {
+  gat_fc_score_weight_block((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, H, F, K, W,
+                            al, ar, Wx, w_max);
+}
+// the same for the layers of a stack in one launch: blockIdx.z picks the layer
+constexpr int SW_BATCH = 16;
+struct ScoreWeightItem {
+  const float *W, *al, *ar;
+  float *Wx, *w_max;
+  int64_t K;
+  int H, F;
+};
+struct ScoreWeightBatch { ScoreWeightItem item[SW_BATCH]; };
+__global__ __launch_bounds__(1024) void gat_fc_score_weight_batch_kernel(ScoreWeightBatch batch) {
+  const ScoreWeightItem &it = batch.item[blockIdx.z];
+  const int gx = (int)((it.K + SW_COLS - 1) / SW_COLS), gy = it.H;
+  if ((int)blockIdx.x >= gx || (int)blockIdx.y >= gy) return;
+  gat_fc_score_weight_block((int)blockIdx.x, (int)blockIdx.y, gx, gy, it.H, it.F, it.K, it.W, it.al, it.ar,
+                            it.Wx, it.w_max);
 }
 
 // Backward of tv_gat_fc_score_weight.  dWx [H*F + pad4(2H), K] is the weight gradient of the fc
@@ -1437,6 +1462,39 @@ extern "C" int tv_gat_fc_score_weight(int64_t heads, int64_t feats, int64_t in_f
   hipLaunchKernelGGL(gat_fc_score_weight_kernel, grid, block, 0, (hipStream_t)stream, (int)heads,
                      (int)feats, in_feats, weight, attn_l, attn_r, weight_ext, weight_ext_max);
   TV_LAUNCH_CHECK("tv_gat_fc_score_weight");
+  return TV_OK;
+}
+
+extern "C" int tv_gat_fc_score_weight_batch(int64_t count, const int64_t *heads, const int64_t *feats,
+                                            const int64_t *in_feats, const float *const *weight,
+                                            const float *const *attn_l, const float *const *attn_r,
+                                            float *const *weight_ext, float *const *weight_ext_max,
+                                            void *stream) {
+  TV_REQUIRE(count >= 0 && count <= SW_BATCH, "tv_gat_fc_score_weight_batch: at most %d layers per call",
+             SW_BATCH);
+  if (count == 0) return TV_OK;
+  TV_REQUIRE(heads && feats && in_feats && weight && attn_l && attn_r && weight_ext && weight_ext_max,
+             "tv_gat_fc_score_weight_batch: null array");
+  ScoreWeightBatch batch = {};
+  int64_t gx = 0, gy = 0;
+  for (int64_t i = 0; i < count; ++i) {
+    if (int rc = check_shape("tv_gat_fc_score_weight_batch", 0, 1, heads[i], feats[i])) return rc;
+    TV_REQUIRE(in_feats[i] >= 1, "tv_gat_fc_score_weight_batch: in_feats must be positive");
+    TV_REQUIRE(weight[i] && attn_l[i] && attn_r[i] && weight_ext[i] && weight_ext_max[i],
+               "tv_gat_fc_score_weight_batch: null pointer");
+    const int64_t bx = tv_cdiv(in_feats[i], SW_COLS);
+    // (the maxima go to one slot per workgroup: no atomics, nothing to clear)
+    TV_REQUIRE(bx * heads[i] <= 256, "tv_gat_fc_score_weight_batch: layer %lld needs %lld workgroups (> 256)",
+               (long long)i, (long long)(bx * heads[i]));
+    ScoreWeightItem &it = batch.item[i];
+    it.W = weight[i]; it.al = attn_l[i]; it.ar = attn_r[i]; it.Wx = weight_ext[i]; it.w_max = weight_ext_max[i];
+    it.K = in_feats[i]; it.H = (int)heads[i]; it.F = (int)feats[i];
+    if (bx > gx) gx = bx;
+    if (heads[i] > gy) gy = heads[i];
+  }
+  hipLaunchKernelGGL(gat_fc_score_weight_batch_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)count),
+                     dim3(1024), 0, (hipStream_t)stream, batch);
+  TV_LAUNCH_CHECK("tv_gat_fc_score_weight_batch");
   return TV_OK;
 }
 

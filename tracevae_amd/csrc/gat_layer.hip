@@ -102,9 +102,11 @@ extern "C" int tv_gat_layer_train_fwd(
     const float *in_gamma, const float *in_beta, float *in_running_mean, float *in_running_var,
     float *in_coeffs, const float *weight, const float *attn_l, const float *attn_r,
     const float *bias, const float *stats_row_weight, float *weight_ext, float *ft, float *out,
-    float *alpha, float *out_stats, float *x_max, int x_max_state, float *w_max, void *workspace,
-    int64_t workspace_bytes, void *stream) {
+    float *alpha, float *out_stats, float *x_max, int x_max_state, float *w_max, int w_prepared,
+    void *workspace, int64_t workspace_bytes, void *stream) {
   TV_REQUIRE(rows >= 0 && in_feats >= 1 && heads >= 1 && feats >= 1, "tv_gat_layer_train_fwd: bad sizes");
+  TV_REQUIRE(w_prepared == 0 || w_prepared == 3 || w_prepared == 4,
+             "tv_gat_layer_train_fwd: w_prepared must be 0, 3 or 4 (tv_gemm_f32_ex states of B)");
   if (rows == 0) return TV_OK;
   TV_REQUIRE(x && weight && attn_l && attn_r && bias && weight_ext && ft && out && x_max && w_max,
              "tv_gat_layer_train_fwd: null pointer");
@@ -123,11 +125,15 @@ extern "C" int tv_gat_layer_train_fwd(
     x_max_state = bound ? 2 : 1;
     scale = sc; shift = sh;
   }
-  if (int rc = tv_gat_fc_score_weight(heads, feats, in_feats, weight, attn_l, attn_r, weight_ext, w_max, stream))
-    return rc;
+  // the extended weight: written here, or handed over as the plane image that a call for the whole
+  // stack prepared (tv_gat_fc_score_weight_batch + tv_gemm_prepare_b_batch)
+  if (!w_prepared)
+    if (int rc = tv_gat_fc_score_weight(heads, feats, in_feats, weight, attn_l, attn_r, weight_ext, w_max, stream))
+      return rc;
   if (int rc = tv_gemm_f32_ex(0, 1, rows, width, in_feats, x, x_stride, weight_ext, in_feats, ft, width,
                               nullptr, nullptr, 0, deferred ? 1 : 0, scale, shift, slope, x_max,
-                              x_max_state, w_max, 2, workspace, workspace_bytes, stream))
+                              x_max_state, w_max, w_prepared ? w_prepared : 2, workspace, workspace_bytes,
+                              stream))
     return rc;
   if (int rc = tv_gat_aggregate_fwd(rows, 1, heads, feats, indptr, indices, ft, ft + hf, ft + hf + heads,
                                     bias, out, alpha, out_stats, out_stats ? stats_row_weight : nullptr,

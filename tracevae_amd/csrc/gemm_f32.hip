@@ -426,12 +426,11 @@ struct PlaneTile {
 // B (the small operand of a layer product: the weight matrix) split once per call instead of
 // once per output tile: one workgroup writes the 24 KB LDS image of one (n-tile, k-tile) pair,
 // zero outside the matrix.  kx: B is stored [k][n] (trans_b = 0), else [n][k].
-__global__ __launch_bounds__(256) void gemm_split_b_kernel(const float *B, int64_t ldb, int kx,
-                                                           int64_t N, int64_t K, int64_t ktiles,
-                                                           char *planes) {
+__device__ __forceinline__ void gemm_split_b_block(int64_t block, const float *B, int64_t ldb, int kx,
+                                                   int64_t N, int64_t K, int64_t ktiles, char *planes) {
   const int t = threadIdx.x;
-  const int64_t tn = blockIdx.x / ktiles, kt = blockIdx.x % ktiles;
-  char *image = planes + (int64_t)blockIdx.x * OPERAND_BYTES;
+  const int64_t tn = block / ktiles, kt = block % ktiles;
+  char *image = planes + block * OPERAND_BYTES;
   // thread -> (4 rows, 4 consecutive k) as the in-kernel split, following the storage order
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -956,14 +955,19 @@ __global__ __launch_bounds__(1024) void gemm_amax_kernel(const float *__restrict
 
 // B split once per call into the fp16 LDS images of its tiles (16 KB each), scaled by the power
 // of two that `slots` (its gemm_amax_kernel result) gives.  Layout of a plane as in the bf16 form.
-__global__ __launch_bounds__(256) void gemm_split_b_h_kernel(const float *B, int64_t ldb, int kx,
-                                                             int64_t N, int64_t K, int64_t ktiles,
-                                                             const float *slots, char *planes) {
+__global__ __launch_bounds__(256) void gemm_split_b_kernel(const float *B, int64_t ldb, int kx,
+                                                           int64_t N, int64_t K, int64_t ktiles,
+                                                           char *planes) {
+  gemm_split_b_block(blockIdx.x, B, ldb, kx, N, K, ktiles, planes);
+}
+__device__ __forceinline__ void gemm_split_b_h_block(int64_t block, const float *B, int64_t ldb,
+                                                     int kx, int64_t N, int64_t K, int64_t ktiles,
+                                                     const float *slots, char *planes) {
   const int t = threadIdx.x;
   float sb, inv;
   pow2_scale(reduce_amax_slots(slots, t & 63), sb, inv);
-  const int64_t tn = blockIdx.x / ktiles, kt = blockIdx.x % ktiles;
-  char *image = planes + (int64_t)blockIdx.x * H_OPERAND_BYTES;
+  const int64_t tn = block / ktiles, kt = block % ktiles;
+  char *image = planes + block * H_OPERAND_BYTES;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int row = kx ? (t & 31) + 32 * a : (t >> 3) + 32 * a;
@@ -982,6 +986,30 @@ __global__ __launch_bounds__(256) void gemm_split_b_h_kernel(const float *B, int
     *reinterpret_cast<uint2 *>(dst) = make_uint2(p01, p23);
     *reinterpret_cast<uint2 *>(dst + PLANE_BYTES) = make_uint2(q01, q23);
   }
+}
+__global__ __launch_bounds__(256) void gemm_split_b_h_kernel(const float *B, int64_t ldb, int kx,
+                                                             int64_t N, int64_t K, int64_t ktiles,
+                                                             const float *slots, char *planes) {
+  gemm_split_b_h_block(blockIdx.x, B, ldb, kx, N, K, ktiles, slots, planes);
+}
+
+// Several small operands split in ONE launch (tv_gemm_prepare_b_batch: the weights of a stack of
+// layers, each in the two orientations its forward product and its input gradient read):
+// blockIdx.y picks the operand, blockIdx.x its (column tile, k-tile) image.
+constexpr int SPLIT_BATCH = 32;
+struct SplitItem {
+  const float *b;
+  const float *slots;     // fp16 form: the operand's partial maxima
+  char *planes;
+  int64_t ldb, n, k, ktiles, blocks;
+  int kx, form;
+};
+struct SplitBatch { SplitItem item[SPLIT_BATCH]; };
+__global__ __launch_bounds__(256) void gemm_split_b_batch_kernel(SplitBatch batch) {
+  const SplitItem &it = batch.item[blockIdx.y];
+  if ((int64_t)blockIdx.x >= it.blocks) return;
+  if (it.form) gemm_split_b_h_block(blockIdx.x, it.b, it.ldb, it.kx, it.n, it.k, it.ktiles, it.slots, it.planes);
+  else gemm_split_b_block(blockIdx.x, it.b, it.ldb, it.kx, it.n, it.k, it.ktiles, it.planes);
 }
 
 __device__ __forceinline__ void read_set_h(const char *lds, int row0, int lane, int step, f16x8 (&f)[2]) {
@@ -1692,10 +1720,15 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
              void *stream, float *a_max = nullptr, int a_max_state = 0, float *b_max = nullptr,
              int b_max_state = 0) {
   TV_REQUIRE(m >= 0 && n >= 0 && k >= 0, "tv_gemm_f32: negative size");
-  TV_REQUIRE(a_max_state >= 0 && a_max_state <= 2 && b_max_state >= 0 && b_max_state <= 2 &&
-                 (a_max || a_max_state == 0) && (b_max || b_max_state == 0),
+  TV_REQUIRE(a_max_state >= 0 && a_max_state <= 2 && b_max_state >= 0 && b_max_state <= 4 &&
+                 (a_max || a_max_state == 0) && (b_max || b_max_state == 0 || b_max_state == 3),
              "tv_gemm_f32_ex: operand-maximum state must be 0 (none), 1 (compute into the buffer) "
-             "or 2 (the buffer is valid), with a buffer for 1 and 2");
+             "or 2 (the buffer is valid), with a buffer for 1 and 2; for B also 3 / 4 (b is a "
+             "plane image from tv_gemm_prepare_b_batch: bf16 / fp16 form)");
+  // B handed over as a ready-made plane image (tv_gemm_prepare_b_batch)
+  const int b_prepared = b_max_state >= 3 ? (b_max_state == 4 ? 1 : 0) : -1;
+  if (b_max_state == 3) b_max_state = 0;
+  if (b_max_state == 4) b_max_state = 2;
   if (m == 0 || n == 0) return TV_OK;
   TV_REQUIRE(a && b && c, "tv_gemm_f32: null operand");
   TV_REQUIRE(lda >= (trans_a ? m : k), "tv_gemm_f32: lda %lld too small", (long long)lda);
@@ -1780,7 +1813,14 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
   // 40: 79 -> 70 us, tools/narrow_gemm_lab.py)
   const bool take_wide = plan.wide && presplit && !trans_a && a_rows16 && !row_scale && !accumulate &&
                          act_operand != 2 && k >= 64 && n >= 64;
-  if (presplit) {
+  if (b_prepared >= 0) {
+    TV_REQUIRE(presplit && b_prepared == (take_wide ? 1 : 0),
+               "tv_gemm_f32_ex: the prepared B image is of form %d but this product (m %lld n %lld k %lld) "
+               "takes %s", b_prepared, (long long)m, (long long)n, (long long)k,
+               !presplit ? "no pre-split B" : (take_wide ? "the fp16 form" : "the bf16 form"));
+    TV_REQUIRE(((uintptr_t)b & 15) == 0, "tv_gemm_f32_ex: the prepared B image must be 16-byte aligned");
+    g.b_planes = reinterpret_cast<const char *>(b);
+  } else if (presplit) {
     TV_REQUIRE(((uintptr_t)workspace & 15) == 0, "tv_gemm_f32: workspace must be 16-byte aligned");
     char *planes = (char *)workspace + plan.slab_bytes;
     g.b_planes = planes;
@@ -1940,6 +1980,57 @@ int run_gemm(int trans_a, int trans_b, int64_t m, int64_t n, int64_t k, const fl
 }  // namespace
 
 extern "C" int tv_gemm_f32_last_form(void) { return g_last_form; }
+
+// ------------------------------------------------------------------------------------
+// B prepared ahead of the products (tv_gemm_prepare_b_batch): the weights of a stack of layers
+// change once per step, so their plane images - one per orientation: the forward product reads
+// W as [n][k], the input gradient as [k][n] - are all written by ONE launch instead of one
+// launch in front of every product.
+// ------------------------------------------------------------------------------------
+extern "C" int tv_gemm_b_form(int64_t m, int64_t n, int64_t k) {
+  if (m <= 0 || n <= 0 || k <= 0) return -1;
+  const Plan plan = make_plan(m, n, k);
+  if (plan.planes_bytes == 0) return -1;             // B is split inside the kernel
+  return (plan.wide && k >= 64 && n >= 64) ? 1 : 0;  // as run_gemm decides for a plain product
+}
+
+extern "C" int64_t tv_gemm_prepared_b_bytes(int64_t m, int64_t n, int64_t k) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  return make_plan(m, n, k).planes_bytes;
+}
+
+extern "C" int tv_gemm_prepare_b_batch(int64_t count, const int64_t *m, const int64_t *n,
+                                       const int64_t *k, const int *trans_b,
+                                       const float *const *b, const int64_t *ldb,
+                                       const float *const *b_max, void *const *planes,
+                                       void *stream) {
+  TV_REQUIRE(count >= 0 && count <= SPLIT_BATCH, "tv_gemm_prepare_b_batch: at most %d operands per call",
+             SPLIT_BATCH);
+  if (count == 0) return TV_OK;
+  TV_REQUIRE(m && n && k && trans_b && b && ldb && b_max && planes, "tv_gemm_prepare_b_batch: null array");
+  SplitBatch batch = {};
+  int64_t most = 0;
+  for (int64_t i = 0; i < count; ++i) {
+    const int form = tv_gemm_b_form(m[i], n[i], k[i]);
+    TV_REQUIRE(form >= 0, "tv_gemm_prepare_b_batch: operand %lld (m %lld n %lld k %lld) is not pre-split",
+               (long long)i, (long long)m[i], (long long)n[i], (long long)k[i]);
+    TV_REQUIRE(b[i] && planes[i] && (((uintptr_t)planes[i]) & 15) == 0,
+               "tv_gemm_prepare_b_batch: null operand or unaligned image");
+    TV_REQUIRE(ldb[i] >= (trans_b[i] ? k[i] : n[i]), "tv_gemm_prepare_b_batch: ldb too small");
+    TV_REQUIRE(form == 0 || b_max[i], "tv_gemm_prepare_b_batch: the fp16 form needs the operand's maxima");
+    SplitItem &it = batch.item[i];
+    it.b = b[i]; it.slots = b_max[i]; it.planes = (char *)planes[i];
+    it.ldb = ldb[i]; it.n = n[i]; it.k = k[i]; it.ktiles = tv_cdiv(k[i], BK);
+    it.blocks = ((tv_cdiv(n[i], BN) + 1) & ~1ll) * it.ktiles;
+    it.kx = trans_b[i] ? 0 : 1; it.form = form;
+    if (it.blocks > most) most = it.blocks;
+  }
+  TV_REQUIRE(most < (1ll << 31), "tv_gemm_prepare_b_batch: operand too large");
+  hipLaunchKernelGGL(gemm_split_b_batch_kernel, dim3((unsigned)most, (unsigned)count), dim3(256), 0,
+                     (hipStream_t)stream, batch);
+  TV_LAUNCH_CHECK("tv_gemm_prepare_b_batch");
+  return TV_OK;
+}
 
 extern "C" int tv_gemm_profile_begin(void) {
   std::lock_guard<std::mutex> guard(g_profile.lock);

@@ -53,6 +53,8 @@ FUSED_BN_LINEAR = True
 FUSED_GAT_LAYER = True
 # the BatchNorm + LeakyReLU that ends a stack applied inside the stack's tail kernel
 DEFERRED_TAILS = True
+# a stack's extended weights and their plane images built by two launches per stack
+PREPARED_STACK_WEIGHTS = True
 
 
 # ---------------------------------------------------------------------------------------
@@ -262,15 +264,19 @@ class GATConvAgg(nn.Module):
         self.gnn = _GATParams(input_dim, output_dim, num_heads)
         self.normalization = BatchNorm(self.output_dim) if use_batch_norm else None
 
+    def takes_fused_call(self, n_rep: int) -> bool:
+        bn = self.normalization
+        return (bn is not None and bn.training and n_rep == 1 and FUSED_GAT_LAYER and FUSED_BN_LINEAR
+                and not ops.TIMER.enabled)
+
     def forward(self, graph: ops.DeviceGraph, h, n_rep: int = 1, row_weight=None, count=None,
-                defer: bool = False):
+                defer: bool = False, prepared=None):
         """`row_weight` / `count`: rows that stand for several identical rows of the batch
         (compact latency decoder); only the BatchNorm statistics see the difference.
         `defer`: in training mode return a `_DeferredBN` for the next GAT layer to consume."""
         g = self.gnn
         bn = self.normalization
-        if bn is not None and bn.training and n_rep == 1 and FUSED_GAT_LAYER and FUSED_BN_LINEAR \
-                and not ops.TIMER.enabled:
+        if self.takes_fused_call(n_rep):
             deferred = None
             x = h
             if isinstance(h, _DeferredBN):
@@ -280,7 +286,7 @@ class GATConvAgg(nn.Module):
                                              b.eps, b.momentum, h.row_weight, h.count)
                 x = h.x
             out, stats = ops.gat_layer_train(x, g.fc.weight, g.attn_l, g.attn_r, g.bias, graph,
-                                             deferred, LRELU_SLOPE, row_weight)
+                                             deferred, LRELU_SLOPE, row_weight, prepared)
             if defer:
                 return _DeferredBN(out, stats, bn, row_weight, count)
             return bn.forward_lrelu(out, stats, row_weight, count)
@@ -372,8 +378,19 @@ class GNNSequential(nn.Module):
         # wide rows (AvgPooling; GraphConv that aggregates before it multiplies)
         tail_defers = DEFERRED_TAILS and n_rep == 1 and (
             isinstance(tail, _Pooling) or (isinstance(tail, GraphConv) and tail.takes_deferred()))
+        # the weights of the whole stack prepared in two launches (extended weights, plane images
+        # for the fc products and the input gradients) instead of three per layer
+        prepared = [None] * len(layers)
+        if PREPARED_STACK_WEIGHTS and layers and all(
+                isinstance(l, GATConvAgg) and l.takes_fused_call(n_rep) for l in layers):
+            weights = self.__dict__.get('_gat_weights')
+            if weights is None or any(a is not l.gnn.fc.weight for (a, _, _), l in zip(weights, layers)):
+                weights = self.__dict__['_gat_weights'] = [
+                    (l.gnn.fc.weight, l.gnn.attn_l, l.gnn.attn_r) for l in layers]
+            prepared = ops.prepare_gat_layers(weights, graph.num_rows)
         for i, layer in enumerate(layers):
-            h = layer(graph, h, n_rep, row_weight, count, defer=i + 1 < len(layers) or tail_defers)
+            h = layer(graph, h, n_rep, row_weight, count, defer=i + 1 < len(layers) or tail_defers,
+                      prepared=prepared[i])
         if isinstance(tail, _Pooling):
             return tail(tail_arg, h)
         return tail(graph, h, n_rep)

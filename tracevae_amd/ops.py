@@ -609,6 +609,108 @@ class DeferredInput(object):
         self.eps, self.momentum, self.row_weight, self.count = eps, momentum, row_weight, count
 
 
+class PreparedGATWeights(object):
+    """What `prepare_gat_layers` left for one layer: the plane images of its extended weight for
+    the fc product (`fwd`) and for the input gradient (`bwd`), their forms (tv_gemm_f32_ex states
+    3 / 4) and the maxima the fp16 form scaled them by.  Valid for products of `rows` rows until
+    the weights change."""
+    __slots__ = ['rows', 'fwd', 'fwd_state', 'bwd', 'bwd_state', 'w_max']
+
+
+_PREPARE_CACHE: dict = {}
+
+
+def prepare_gat_layers(layers, rows: int):
+    """The extended weights `[W ; A_l W ; A_r W ; 0]` of a stack of GAT layers and their plane
+    images in both orientations, in TWO launches for the whole stack
+    (`tv_gat_fc_score_weight_batch`, `tv_gemm_prepare_b_batch`) instead of three per layer.
+    `layers`: [(weight, attn_l, attn_r)].  Returns a list with a `PreparedGATWeights` per layer, or
+    None where a layer's products do not take a pre-split B (the layer call then builds its
+    weights itself).  The buffers and the argument arrays of a stack are made once and written
+    anew by every call (a stack's weights live at fixed addresses in the flat parameter buffer);
+    what a call returns is valid until the next call for the same stack."""
+    import ctypes
+    ent = _PREPARE_CACHE.get((id(layers), rows))
+    if (ent is not None and ent['layers'] is layers
+            and ent['ptrs'] == [t.data_ptr() for l in layers for t in l]):
+        return _run_prepared(ent, rows)
+    shapes = []
+    for weight, attn_l, attn_r in layers:
+        hf, k = weight.shape
+        heads = int(attn_l.shape[-2])
+        width = hf + score_columns(heads)
+        shapes.append((hf, k, heads, int(attn_l.shape[-1]), width,
+                       hip.query('tv_gemm_b_form', rows, width, k),
+                       hip.query('tv_gemm_b_form', rows, k, width)))
+    key = (tuple((w.data_ptr(), a.data_ptr(), b.data_ptr()) for w, a, b in layers), tuple(shapes))
+    ent = _PREPARE_CACHE.get(key)
+    if ent is None:
+        todo = []
+        for i, ((weight, attn_l, attn_r), (hf, k, heads, feats, width, f_fwd, f_bwd)) in enumerate(
+                zip(layers, shapes)):
+            if (f_fwd < 0 or f_bwd < 0 or k % 4 or (k + 15) // 16 * heads > 256
+                    or not (weight.is_contiguous() and attn_l.is_contiguous() and attn_r.is_contiguous())):
+                continue
+            todo.append((i, weight, attn_l, attn_r, heads, feats, k, width, f_fwd, f_bwd))
+        ent = {'n': len(todo), 'out': [None] * len(layers)}
+        if todo:
+            dev = todo[0][1].device
+            n = len(todo)
+            wx = [torch.empty([t[7], t[6]], dtype=_f32, device=dev) for t in todo]
+            boxes = [OperandMax(dev) for _ in todo]
+            img_f = [torch.empty([hip.query('tv_gemm_prepared_b_bytes', rows, t[7], t[6])],
+                                 dtype=torch.uint8, device=dev) for t in todo]
+            img_b = [torch.empty([hip.query('tv_gemm_prepared_b_bytes', rows, t[6], t[7])],
+                                 dtype=torch.uint8, device=dev) for t in todo]
+            i64, ptrs = ctypes.c_int64 * n, ctypes.c_void_p * n
+            ent['score'] = (n, i64(*[t[4] for t in todo]), i64(*[t[5] for t in todo]),
+                            i64(*[t[6] for t in todo]), ptrs(*[t[1].data_ptr() for t in todo]),
+                            ptrs(*[t[2].data_ptr() for t in todo]), ptrs(*[t[3].data_ptr() for t in todo]),
+                            ptrs(*[w.data_ptr() for w in wx]), ptrs(*[b.slots.data_ptr() for b in boxes]))
+            # two images per layer: [n][k] for x . W_ext^T, [k][n] for dft . W_ext
+            m2 = 2 * n
+            i64b, ptrb, i32b = ctypes.c_int64 * m2, ctypes.c_void_p * m2, ctypes.c_int * m2
+            ns, ks, tb, bs, lds, mx, pl = [], [], [], [], [], [], []
+            for j, t in enumerate(todo):
+                k, width = t[6], t[7]
+                for (nn, kk, tt, img) in ((width, k, 1, img_f[j]), (k, width, 0, img_b[j])):
+                    ns.append(nn); ks.append(kk); tb.append(tt)
+                    bs.append(wx[j].data_ptr()); lds.append(k); mx.append(boxes[j].slots.data_ptr())
+                    pl.append(img.data_ptr())
+            ent['rows'] = i64b(*([rows] * m2))
+            ent['split'] = (i64b(*ns), i64b(*ks), i32b(*tb), ptrb(*bs), i64b(*lds), ptrb(*mx), ptrb(*pl))
+            ent['keep'] = (wx, boxes, img_f, img_b, [t[1:4] for t in todo])
+            for j, t in enumerate(todo):
+                p = PreparedGATWeights()
+                p.fwd, p.fwd_state = img_f[j], 3 + t[8]
+                p.bwd, p.bwd_state = img_b[j], 3 + t[9]
+                boxes[j].valid = True
+                p.w_max = boxes[j]
+                ent['out'][t[0]] = p
+        _PREPARE_CACHE[key] = ent
+    # a caller that keeps its list of layers alive finds the entry by the list and the row count
+    # alone the next time (the forms of the products depend on the row count)
+    if len(_PREPARE_CACHE) < 65536:
+        _PREPARE_CACHE[(id(layers), rows)] = dict(ent, layers=layers,
+                                                  ptrs=[t.data_ptr() for l in layers for t in l])
+    return _run_prepared(ent, rows)
+
+
+def _run_prepared(ent, rows: int):
+    if ent['n']:
+        m2 = 2 * ent['n']
+        arr = ent['rows']
+        if arr[0] != rows:
+            for q in range(m2):
+                arr[q] = rows
+        hip.call('tv_gat_fc_score_weight_batch', *ent['score'])
+        hip.call('tv_gemm_prepare_b_batch', m2, arr, *ent['split'])
+        for p in ent['out']:
+            if p is not None:
+                p.rows = rows
+    return ent['out']
+
+
 class _GATLayerTrain(Function):
     """One GATConvAgg layer of a training step as ONE library call each way
     (`tv_gat_layer_train_fwd / _bwd`): the launches of `_BNLReLULinear` (or `_LinearScores`) and
@@ -618,7 +720,7 @@ class _GATLayerTrain(Function):
 
     @staticmethod
     def forward(ctx, x, in_gamma, in_beta, weight, attn_l, attn_r, bias, graph, deferred, slope,
-                stats_row_weight):
+                stats_row_weight, prepared=None):
         x_in = x
         x = _check(x, 'x')
         weight, bias = _check(weight, 'weight'), _check(bias, 'bias')
@@ -639,13 +741,15 @@ class _GATLayerTrain(Function):
                 raise ValueError('Expected more than 1 value per channel when training')
             coeffs = torch.empty([4, (k + 3) // 4 * 4], dtype=_f32, device=dev)
             in_gamma, in_beta = _check(in_gamma, 'gamma'), _check(in_beta, 'beta')
-        wx = torch.empty([width, k], dtype=_f32, device=dev)
+        if prepared is not None and (prepared.rows != rows or x.stride(0) % 4 or x.data_ptr() % 16):
+            prepared = None             # (made for other products than this one)
+        wx = prepared.fwd if prepared is not None else torch.empty([width, k], dtype=_f32, device=dev)
         ft = torch.empty([rows, width], dtype=_f32, device=dev)
         out = torch.empty([rows, hf], dtype=_f32, device=dev)
         alpha = torch.empty([graph.num_edges, heads], dtype=_f32, device=dev)
         stats = torch.empty([hip.query('tv_stat_blocks', rows), 2, hf], dtype=_f32, device=dev)
         x_max = (operand_max(x_in) if (x is x_in and deferred is None) else None) or OperandMax(dev)
-        w_max = OperandMax(dev)
+        w_max = prepared.w_max if prepared is not None else OperandMax(dev)
         wsb = hip.query('tv_gat_layer_workspace_bytes', rows, k, heads, feats, graph.num_edges)
         ws = _workspace(wsb, dev)
         d = deferred
@@ -658,11 +762,14 @@ class _GATLayerTrain(Function):
                  hip.ptr(coeffs), hip.ptr(weight), hip.ptr(al), hip.ptr(ar), hip.ptr(bias),
                  hip.ptr(stats_row_weight), hip.ptr(wx), hip.ptr(ft), hip.ptr(out), hip.ptr(alpha),
                  hip.ptr(stats), x_max.slots.data_ptr(), 2 if x_max.valid else 1,
-                 w_max.slots.data_ptr(), hip.ptr(ws), wsb)
+                 w_max.slots.data_ptr(), prepared.fwd_state if prepared is not None else 0,
+                 hip.ptr(ws), wsb)
         form = int(hip.lib().tv_gemm_f32_last_form())
         x_max.valid = x_max.valid or form != 0 or (d is not None and k <= 2048)
         w_max.valid = True          # written with weight_ext
-        ctx.save_for_backward(x, wx, ft, alpha, weight, al, ar,
+        # (backward: the image for the input gradient when the weights were prepared)
+        ctx.prepared = prepared
+        ctx.save_for_backward(x, wx if prepared is None else prepared.bwd, ft, alpha, weight, al, ar,
                               *((coeffs, in_gamma, in_beta) if d else ()))
         ctx.graph, ctx.dims = graph, (rows, k, heads, feats)
         ctx.deferred = d is not None
@@ -678,7 +785,7 @@ class _GATLayerTrain(Function):
     @once_differentiable
     def backward(ctx, dout, _dstats):
         if dout is None:
-            return (None,) * 11
+            return (None,) * 12
         x, wx, ft, alpha, weight, al, ar = ctx.saved_tensors[:7]
         coeffs = in_gamma = in_beta = None
         if ctx.deferred:
@@ -705,23 +812,25 @@ class _GATLayerTrain(Function):
                  hip.ptr(in_gamma), hip.ptr(in_beta), ctx.slope, hip.ptr(ctx.row_weight), ctx.count,
                  hip.ptr(weight), hip.ptr(al), hip.ptr(ar), hip.ptr(wx), hip.ptr(ft), hip.ptr(alpha),
                  hip.ptr(dout), ctx.x_max.slots.data_ptr(), 2 if ctx.x_max.valid else 1,
-                 ctx.w_max.slots.data_ptr(), 2 if ctx.w_max.valid else 1, int(need_dx), int(need_dw),
+                 ctx.w_max.slots.data_ptr(),
+                 ctx.prepared.bwd_state if ctx.prepared is not None else (2 if ctx.w_max.valid else 1),
+                 int(need_dx), int(need_dw),
                  hip.ptr(dwx), hip.ptr(dal), hip.ptr(dar), hip.ptr(dbias), hip.ptr(dx),
                  hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(ws), wsb)
         dw = dwx[:hf] if need_dw else None
         if need_dw:
             dal, dar = dal.reshape(ctx.attn_shape), dar.reshape(ctx.attn_shape)
-        return dx, dgamma, dbeta, dw, dal, dar, dbias, None, None, None, None
+        return dx, dgamma, dbeta, dw, dal, dar, dbias, None, None, None, None, None
 
 
 def gat_layer_train(x, weight, attn_l, attn_r, bias, graph: DeviceGraph,
                     deferred: Optional[DeferredInput] = None, slope: float = 0.01,
-                    stats_row_weight=None):
+                    stats_row_weight=None, prepared: Optional[PreparedGATWeights] = None):
     """`(out, stats_partial)` of one GAT layer in training mode: fc (+ the deferred BatchNorm +
     LeakyReLU of its input) -> attention scores -> aggregation with column statistics of `out`."""
     return _GATLayerTrain.apply(x, deferred.gamma if deferred else None,
                                 deferred.beta if deferred else None, weight, attn_l, attn_r, bias,
-                                graph, deferred, slope, stats_row_weight)
+                                graph, deferred, slope, stats_row_weight, prepared)
 
 
 # ---------------------------------------------------------------------------------------
