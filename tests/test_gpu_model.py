@@ -603,3 +603,49 @@ def test_fused_gat_layer_calls_are_bit_equal_to_the_operator_level_path(device, 
     assert torch.equal(a['flat'], b['flat'])
     for k in b['stats']:
         assert torch.equal(a['stats'][k], b['stats'][k]), k
+
+
+@pytest.mark.parametrize('latency_only', [False, True])
+def test_prepared_stack_weights_are_bit_equal_to_per_layer_preparation(device, monkeypatch,
+                                                                       latency_only):
+    """The extended weights and plane images of a stack built by two launches per stack
+    (`ops.prepare_gat_layers`: `tv_gat_fc_score_weight_batch`, `tv_gemm_prepare_b_batch`, images
+    handed to the products as states 3 / 4) against each layer call preparing its own: two whole
+    training steps in a row (the second writes the kept buffers anew, after an update) are bit
+    for bit the same, at a size whose products do take a pre-split B."""
+    import tracevae_amd.model as model
+    import tracevae_amd.ops as ops
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.train import Trainer
+    V, M = 60, 32
+    results, taken = {}, []
+    real = ops.prepare_gat_layers
+
+    def spy(layers, rows):
+        out = real(layers, rows)
+        taken.extend(p is not None for p in out)
+        return out
+    monkeypatch.setattr(ops, 'prepare_gat_layers', spy)
+    for prepared in (True, False):
+        monkeypatch.setattr(model, 'PREPARED_STACK_WEIGHTS', prepared)
+        cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 128, 3, 160, seed=29)
+        B = len(flat)
+        trainer = Trainer(vae, cfg, latency_only=latency_only, world_size=1)
+        steps = []
+        for step in range(2):
+            g = torch.Generator().manual_seed(3 + step)
+            eps = {'z': torch.randn(B, 10, generator=g), 'z2': torch.randn(B, 10, generator=g)}
+            G = TraceGraphBatch.from_store(store, np.arange(B), M)
+            out = trainer.local_gradients(G, eps)
+            grad = trainer.flat.grad.clone()
+            trainer.update()
+            steps.append(dict(loss=out['loss'].detach().clone(), grad=grad,
+                              flat=trainer.flat.flat.clone()))
+        results[prepared] = steps
+    # (a stack's first layer may stay with its own preparation: input widths that are no
+    # multiple of 4)
+    assert taken and 2 * sum(taken) > len(taken), 'this size does not exercise the prepared images'
+    for a, b in zip(results[True], results[False]):
+        assert torch.equal(a['loss'], b['loss'])
+        assert torch.equal(a['grad'], b['grad']) and float(a['grad'].abs().max()) > 0
+        assert torch.equal(a['flat'], b['flat'])

@@ -1396,3 +1396,50 @@ def test_operand_maxima_from_the_producing_kernels(device):
     want = act @ w2.double().t()
     scale = act.abs() @ w2.double().abs().t()
     assert float(((got.double() - want).abs() / scale).max()) < 2e-6
+
+
+@pytest.mark.parametrize('m,n,k', [(4096, 600, 500), (4096, 96, 40), (2500, 50, 300), (3000, 128, 132)])
+@pytest.mark.parametrize('trans_b', [0, 1])
+def test_gemm_takes_a_prepared_image_of_b(device, m, n, k, trans_b):
+    """`tv_gemm_prepare_b_batch` + `tv_gemm_f32_ex` states 3 / 4 (B is a plane image made
+    beforehand, several operands per launch) against the call that splits B itself: the same
+    bits, both forms, both orientations of B; a wrong form is refused."""
+    import ctypes
+    from tracevae_amd import hip, ops
+    g = torch.Generator().manual_seed(m + n + k + trans_b)
+
+    def product(mm, nn, kk, tb, a, b, ldb, box, state, out):
+        ws = torch.empty([hip.query('tv_gemm_f32_workspace_bytes', mm, nn, kk)], dtype=torch.uint8,
+                         device=device)
+        hip.call('tv_gemm_f32_ex', 0, tb, mm, nn, kk, a.data_ptr(), kk, b.data_ptr(), ldb,
+                 out.data_ptr(), nn, None, None, 0, 0, None, None, 0.0, None, 0,
+                 box.slots.data_ptr(), state, ws.data_ptr(), ws.numel())
+        return out
+
+    a = torch.randn(m, k, generator=g).to(device)
+    b = (torch.randn(n, k, generator=g) if trans_b else torch.randn(k, n, generator=g)).to(device)
+    form = hip.query('tv_gemm_b_form', m, n, k)
+    assert form in (0, 1)
+    box = ops.OperandMax(device)
+    want = product(m, n, k, trans_b, a, b, b.stride(0), box, 1, torch.empty(m, n, device=device))
+    # a second operand in the same launch: the batch kernel finds its item by block ranges
+    m2, n2, k2 = 4096, 132, 76
+    a2 = torch.randn(m2, k2, generator=g).to(device)
+    b2 = torch.randn(k2, n2, generator=g).to(device)
+    form2 = hip.query('tv_gemm_b_form', m2, n2, k2)
+    box2 = ops.OperandMax(device)
+    want2 = product(m2, n2, k2, 0, a2, b2, n2, box2, 1, torch.empty(m2, n2, device=device))
+    image = torch.empty([hip.query('tv_gemm_prepared_b_bytes', m, n, k)], dtype=torch.uint8, device=device)
+    image2 = torch.empty([hip.query('tv_gemm_prepared_b_bytes', m2, n2, k2)], dtype=torch.uint8,
+                         device=device)
+    i64, i32, ptrs = ctypes.c_int64 * 2, ctypes.c_int * 2, ctypes.c_void_p * 2
+    hip.call('tv_gemm_prepare_b_batch', 2, i64(m2, m), i64(n2, n), i64(k2, k), i32(0, trans_b),
+             ptrs(b2.data_ptr(), b.data_ptr()), i64(n2, b.stride(0)),
+             ptrs(box2.slots.data_ptr(), box.slots.data_ptr()), ptrs(image2.data_ptr(), image.data_ptr()))
+    got = product(m, n, k, trans_b, a, image, b.stride(0), box, 3 + form, torch.empty(m, n, device=device))
+    assert torch.equal(got, want)
+    got2 = product(m2, n2, k2, 0, a2, image2, n2, box2, 3 + form2, torch.empty(m2, n2, device=device))
+    assert torch.equal(got2, want2)
+    assert rel_err(want, a @ (b.t() if trans_b else b)) < 1e-5
+    with pytest.raises(hip.HipLibraryError):
+        product(m, n, k, trans_b, a, image, b.stride(0), box, 4 - form, got)
