@@ -634,6 +634,10 @@ def prepare_gat_layers(layers, rows: int):
     if (ent is not None and ent['layers'] is layers
             and ent['ptrs'] == [t.data_ptr() for l in layers for t in l]):
         return _run_prepared(ent, rows)
+    if len(_PREPARE_CACHE) >= 4096:
+        # entries of models that are gone, or of thousands of row counts: start over (what a
+        # running step still needs it holds itself, through the objects it was handed)
+        _PREPARE_CACHE.clear()
     shapes = []
     for weight, attn_l, attn_r in layers:
         hf, k = weight.shape
@@ -690,9 +694,8 @@ def prepare_gat_layers(layers, rows: int):
         _PREPARE_CACHE[key] = ent
     # a caller that keeps its list of layers alive finds the entry by the list and the row count
     # alone the next time (the forms of the products depend on the row count)
-    if len(_PREPARE_CACHE) < 65536:
-        _PREPARE_CACHE[(id(layers), rows)] = dict(ent, layers=layers,
-                                                  ptrs=[t.data_ptr() for l in layers for t in l])
+    _PREPARE_CACHE[(id(layers), rows)] = dict(ent, layers=layers,
+                                              ptrs=[t.data_ptr() for l in layers for t in l])
     return _run_prepared(ent, rows)
 
 
