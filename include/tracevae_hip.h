@@ -669,6 +669,22 @@ int tv_optim_step(int kind, int64_t n, float *param, const float *grad, float *s
                   float *state2, const float *grad_norm /* device scalar, nullable */,
                   float clip_norm, float lr, float beta1, float beta2, float eps, int64_t step,
                   void *stream);
+/* tv_optim_step with the NaN decision of the step (train.py:272-274: a NaN loss raises before
+ * optimizer.step()) taken ON THE DEVICE, so that the host does not have to wait for the loss of
+ * every step: `guard` is a device scalar, and nothing is updated when it is NaN (guard_kind 1:
+ * the loss itself) or non-zero (guard_kind 2: the all-reduced count of ranks whose loss was NaN).
+ * The host reads the same scalar one step later (Trainer.finish) and raises then; parameters and optimizer
+ * state are those from before the NaN step, as in the reference.  guard_host (nullable): one
+ * float of PINNED HOST memory (hipHostMalloc; torch's pin_memory) that receives the scalar by a
+ * store from the kernel - visible to the host once an event recorded behind the call has
+ * completed -, so that no device-to-host copy is queued behind the step.  guard NULL /
+ * guard_kind 0: tv_optim_step. */
+int tv_optim_step_guarded(int kind, int64_t n, float *param, const float *grad, float *state1,
+                          float *state2, const float *grad_norm /* device scalar, nullable */,
+                          float clip_norm, float lr, float beta1, float beta2, float eps,
+                          int64_t step, const float *guard /* device scalar, nullable */,
+                          int guard_kind, float *guard_host /* pinned host scalar, nullable */,
+                          void *stream);
 
 /* ------------------------------------------------------------------------------------
  * the scalar end of train_step (tracegnn/models/trace_vae/train.py:229-270):

@@ -245,11 +245,14 @@ def _rccl_single_rank_worker(rank, world, port, tmp):
     G, eps = _shard(0)
     with torch.no_grad():
         tr.flat.flat[:8] = float('nan')
+    state = tr.optimizer.state1.clone()
     try:
-        tr.step(G, eps=eps)
+        tr.step(G, eps=eps)          # returns: the update is guarded by the flag on the device
+        tr.finish()                  # ... and the decision is taken here
         out['nan'] = False
     except NANLossError:
-        out['nan'] = float(tr.flat.bucket[tr.flat.flag_index]) == 1.0
+        out['nan'] = (float(tr.flat.bucket[tr.flat.flag_index]) == 1.0
+                      and torch.equal(tr.optimizer.state1, state))
     # the small collectives around the step: model broadcast, BatchNorm averaging, scalars
     from tracevae_amd.train import all_reduce_sum, average_batch_norm_buffers, broadcast_model
     tr = _trainer(device, 1)

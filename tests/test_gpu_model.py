@@ -649,3 +649,57 @@ def test_prepared_stack_weights_are_bit_equal_to_per_layer_preparation(device, m
         assert torch.equal(a['loss'], b['loss'])
         assert torch.equal(a['grad'], b['grad']) and float(a['grad'].abs().max()) > 0
         assert torch.equal(a['flat'], b['flat'])
+
+
+def test_nan_decision_without_a_host_sync_per_step(device):
+    """train.py:272-274 raises on a NaN loss before `optimizer.step()`.  `Trainer.step` (default
+    `check_nan=True`) reaches the same state without waiting for the loss in every step: the
+    update is guarded on the device (`tv_optim_step_guarded`), `NANLossError` comes from the
+    next `step` - ahead of its collective and its update - or from `finish()`.  `check_nan='now'` raises
+    inside the step; a healthy step is bit for bit the unguarded one."""
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.train import NANLossError, Trainer
+    V, M = 60, 16
+
+    def fresh(seed=31):
+        cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 2, 12, seed=seed)
+        B = len(flat)
+        g = torch.Generator().manual_seed(5)
+        eps = {'z': torch.randn(B, 10, generator=g), 'z2': torch.randn(B, 10, generator=g)}
+        return Trainer(vae, cfg, world_size=1), TraceGraphBatch.from_store(store, np.arange(B), M), eps
+
+    # healthy: guarded == unguarded, nothing pending raises
+    a, G, eps = fresh()
+    b, _, _ = fresh()
+    la = a.step(G, eps=eps)['loss']
+    lb = b.step(G, eps=eps, check_nan=False)['loss']
+    a.finish()
+    assert torch.equal(la, lb) and torch.equal(a.flat.flat, b.flat.flat)
+    assert torch.equal(a.optimizer.state1, b.optimizer.state1) and float(a.optimizer.state1.abs().max()) > 0
+
+    # NaN: one good step, then a step whose loss is NaN (a NaN latency target)
+    for how in ('finish', 'next_step', 'now'):
+        tr, G, eps = fresh()
+        tr.step(G, eps=eps)
+        tr.finish()
+        params, state = tr.flat.flat.clone(), tr.optimizer.state1.clone()
+        with torch.no_grad():
+            tr.flat.flat[3] = float('nan')               # a NaN parameter: the loss is NaN
+        params[3] = float('nan')
+        if how == 'now':
+            with pytest.raises(NANLossError):
+                tr.step(G, eps=eps, check_nan='now')
+        else:
+            out = tr.step(G, eps=eps)                    # returns without a sync
+            assert torch.isnan(out['loss'])
+            if how == 'finish':
+                with pytest.raises(NANLossError):
+                    tr.finish()
+            else:
+                with pytest.raises(NANLossError):
+                    tr.step(G, eps=eps)                  # raised ahead of its own update
+            tr.finish()                                  # the decision is taken once
+        # neither parameters nor optimizer state moved in the NaN step
+        keep = ~torch.isnan(params)
+        assert torch.equal(tr.flat.flat[keep], params[keep]) and bool(torch.isnan(tr.flat.flat[3]))
+        assert torch.equal(tr.optimizer.state1, state)

@@ -110,7 +110,18 @@ __global__ __launch_bounds__(256) void optim_step_kernel(int kind, int64_t n, fl
                                                          const float *__restrict__ grad_norm,
                                                          float clip_norm, float lr, float beta1,
                                                          float beta2, float eps, float bc1,
-                                                         float bc2_sqrt) {
+                                                         float bc2_sqrt,
+                                                         const float *__restrict__ guard,
+                                                         int guard_kind, float *guard_copy) {
+  // the NaN decision of the step taken on the device (tv_optim_step_guarded): the same value
+  // for every thread of the grid, so either all of them update or none does
+  if (guard != nullptr) {
+    const float v = guard[0];
+    // the host's copy of the scalar (pinned host memory, mapped into the device's address
+    // space): one 4-byte vector store instead of a device-to-host copy queued behind the step
+    if (guard_copy != nullptr && blockIdx.x == 0 && threadIdx.x == 0) guard_copy[0] = v;
+    if (guard_kind == 1 ? (v != v) : (v != 0.f)) return;
+  }
   float coef = 1.0f;
   if (grad_norm != nullptr && clip_norm > 0.f) {
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
@@ -185,13 +196,25 @@ extern "C" int tv_axpy_masked(int64_t n, float alpha, const float *x, const uint
   return TV_OK;
 }
 
-extern "C" int tv_optim_step(int kind, int64_t n, float *param, const float *grad, float *state1,
-                             float *state2, const float *grad_norm, float clip_norm, float lr,
-                             float beta1, float beta2, float eps, int64_t step, void *stream) {
+static int optim_step(const char *who, int kind, int64_t n, float *param, const float *grad,
+                      float *state1, float *state2, const float *grad_norm, float clip_norm,
+                      float lr, float beta1, float beta2, float eps, int64_t step,
+                      const float *guard, int guard_kind, float *guard_host, void *stream) {
   TV_REQUIRE(kind == 0 || kind == 1, "tv_optim_step: kind must be 0 (RMSprop) or 1 (Adam)");
   TV_REQUIRE(n >= 1 && param && grad && state1, "tv_optim_step: bad arguments");
   TV_REQUIRE(kind == 0 || state2, "tv_optim_step: Adam needs two state buffers");
   TV_REQUIRE(step >= 1, "tv_optim_step: step counts from 1");
+  TV_REQUIRE(guard_kind >= 0 && guard_kind <= 2 && (guard != nullptr) == (guard_kind != 0),
+             "tv_optim_step_guarded: guard_kind 1 (NaN) or 2 (non-zero) with a guard, 0 without");
+  TV_REQUIRE(!guard_host || guard, "tv_optim_step_guarded: guard_host without a guard");
+  float *guard_copy = nullptr;
+  if (guard_host) {
+    // the device's address of the pinned host scalar; fails (instead of faulting in the kernel)
+    // for memory that is not mapped
+    void *mapped = nullptr;
+    TV_HIP(hipHostGetDevicePointer(&mapped, guard_host, 0));
+    guard_copy = (float *)mapped;
+  }
   float bc1 = 1.0f, bc2s = 1.0f;
   if (kind == 1) {
     bc1 = (float)(1.0 - pow((double)beta1, (double)step));
@@ -199,7 +222,23 @@ extern "C" int tv_optim_step(int kind, int64_t n, float *param, const float *gra
   }
   hipLaunchKernelGGL(optim_step_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, kind,
                      n, param, grad, state1, state2, grad_norm, clip_norm, lr, beta1, beta2, eps,
-                     bc1, bc2s);
-  TV_LAUNCH_CHECK("tv_optim_step");
+                     bc1, bc2s, guard, guard_kind, guard_copy);
+  TV_LAUNCH_CHECK(who);
   return TV_OK;
+}
+
+extern "C" int tv_optim_step(int kind, int64_t n, float *param, const float *grad, float *state1,
+                             float *state2, const float *grad_norm, float clip_norm, float lr,
+                             float beta1, float beta2, float eps, int64_t step, void *stream) {
+  return optim_step("tv_optim_step", kind, n, param, grad, state1, state2, grad_norm, clip_norm, lr,
+                    beta1, beta2, eps, step, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int tv_optim_step_guarded(int kind, int64_t n, float *param, const float *grad,
+                                     float *state1, float *state2, const float *grad_norm,
+                                     float clip_norm, float lr, float beta1, float beta2, float eps,
+                                     int64_t step, const float *guard, int guard_kind,
+                                     float *guard_host, void *stream) {
+  return optim_step("tv_optim_step_guarded", kind, n, param, grad, state1, state2, grad_norm,
+                    clip_norm, lr, beta1, beta2, eps, step, guard, guard_kind, guard_host, stream);
 }

@@ -165,7 +165,11 @@ class FlatOptimizer(object):
     def set_lr(self, lr: float) -> None:
         self.lr = float(lr)
 
-    def step(self, global_clip_norm: Optional[float]) -> None:
+    def step(self, global_clip_norm: Optional[float], guard: Optional[torch.Tensor] = None,
+             guard_kind: int = 0, guard_host: Optional[torch.Tensor] = None) -> None:
+        """`guard` (a device scalar): the update is skipped on the device when it is NaN
+        (guard_kind 1) or non-zero (guard_kind 2) - `tv_optim_step_guarded`; `guard_host`
+        (one pinned host float) receives the scalar from the kernel."""
         n = self.end - self.start
         p = self.flat.flat[self.start:self.end]
         g = self.flat.grad[self.start:self.end]
@@ -180,9 +184,11 @@ class FlatOptimizer(object):
             kind, b1, b2 = 0, 0.0, self.alpha
         else:
             kind, (b1, b2) = 1, self.betas
-        hip.call('tv_optim_step', kind, n, hip.ptr(p), hip.ptr(g), hip.ptr(self.state1),
+        hip.call('tv_optim_step_guarded', kind, n, hip.ptr(p), hip.ptr(g), hip.ptr(self.state1),
                  hip.ptr(self.state2), norm_ptr, float(global_clip_norm or 0.0), self.lr,
-                 float(b1), float(b2), float(self.eps), self.steps)
+                 float(b1), float(b2), float(self.eps), self.steps,
+                 hip.ptr(guard), guard_kind if guard is not None else 0,
+                 guard_host.data_ptr() if guard_host is not None else None)
 
 
 def compute_train_loss(chain, train_cfg, l2_value: Optional[torch.Tensor] = None,
@@ -232,6 +238,7 @@ class Trainer(object):
         # nothing): lets a one-GPU box execute the RCCL code path itself - communicator bound to
         # the device, all-reduce of [gradient range | NaN flag] in device memory
         self.exchange_single_rank = False
+        self._nan_pending, self._nan_host = None, None
         self.set_phase(latency_only)
 
     # -- phases ------------------------------------------------------------------------
@@ -303,20 +310,68 @@ class Trainer(object):
                      hip.ptr(self.l2_mask), hip.ptr(f.grad))
         return out
 
-    def update(self) -> None:
+    def update(self, guard: Optional[torch.Tensor] = None, guard_kind: int = 0,
+               guard_host: Optional[torch.Tensor] = None) -> None:
         """Clip by global norm + RMSprop / Adam over the trained range of the flat buffer."""
-        self.optimizer.step(self.train_cfg.global_clip_norm)
+        if guard is None:
+            self.optimizer.step(self.train_cfg.global_clip_norm)
+        else:
+            self.optimizer.step(self.train_cfg.global_clip_norm, guard, guard_kind, guard_host)
 
-    def step(self, G: TraceGraphBatch, eps=None, check_nan: bool = True) -> Dict[str, torch.Tensor]:
+    def step(self, G: TraceGraphBatch, eps=None, check_nan=True) -> Dict[str, torch.Tensor]:
         """One training step.  With several ranks every rank makes exactly the same sequence of
         collectives (one all-reduce per step) and takes the same NaN decision, so a NaN on one
-        rank raises `NANLossError` on all of them instead of leaving the others blocked."""
+        rank raises `NANLossError` on all of them instead of leaving the others blocked.
+
+        The reference reads the loss back in every step and raises before `optimizer.step()`
+        when it is NaN (train.py:272-274).  `check_nan=True` gives the same outcome without
+        making the host wait for the GPU in every step: the update is guarded by the loss (or
+        the all-reduced NaN count) ON THE DEVICE - a NaN step changes neither parameters nor
+        optimizer state -, the optimizer kernel stores the scalar to pinned host memory, and
+        `NANLossError` is raised by the next `step` - once its forward and backward are issued,
+        so that the GPU has work while the host looks at the step before; ahead of its
+        collective and its update - or by `finish()` (the epoch loop calls it when an epoch's
+        steps are issued).  `check_nan='now'` waits for the loss inside the step, as the
+        reference does (and as any step does whose buffers are in host memory);
+        `check_nan=False` neither checks nor guards."""
         out = self.local_gradients(G, eps)
+        if check_nan:
+            self.finish()
         self.exchange(out['loss'])
-        if check_nan and self.loss_is_nan(out['loss']):     # host sync, like train.py:273
-            raise NANLossError(self.epoch)
-        self.update()
+        if check_nan is True and self.flat.flat.is_cuda:
+            guard, kind = self._nan_guard(out['loss'])
+            if self._nan_host is None:
+                self._nan_host = torch.zeros(1, dtype=torch.float32, pin_memory=True)
+                self._nan_value = self._nan_host.numpy()
+                self._nan_event = torch.cuda.Event()
+            self.update(guard, kind, self._nan_host)     # the kernel stores the scalar there
+            self._nan_event.record()
+            self._nan_pending = (kind, self.epoch)
+        else:
+            if check_nan and self.loss_is_nan(out['loss']):     # host sync, like train.py:273
+                raise NANLossError(self.epoch)
+            self.update()
         return {k: v.detach() for k, v in out.items() if k != 'chain'}
+
+    def _nan_guard(self, loss: torch.Tensor):
+        if self.world_size > 1 or self.exchange_single_rank:
+            f = self.flat
+            return f.bucket[f.flag_index:f.flag_index + 1], 2    # ranks whose loss was NaN
+        return loss.detach().reshape(1), 1
+
+    def finish(self) -> None:
+        """Take the NaN decision of the last step issued with `check_nan=True`: waits for that
+        step's loss (long known when the next step begins) and raises `NANLossError` with the
+        epoch of the step."""
+        pending = self._nan_pending
+        if pending is None:
+            return
+        self._nan_pending = None
+        self._nan_event.synchronize()
+        kind, epoch = pending
+        v = float(self._nan_value[0])
+        if math.isnan(v) if kind == 1 else v != 0.0:
+            raise NANLossError(epoch)
 
     def loss_is_nan(self, loss: torch.Tensor) -> bool:
         if self.world_size > 1 or self.exchange_single_rank:
@@ -507,6 +562,7 @@ def run_training(trainer: 'Trainer', train_stream: Iterable[TraceGraphBatch], tr
         t0, losses = time.perf_counter(), []
         for G in train_stream:
             losses.append(trainer.step(G)['loss'])
+        trainer.finish()                                 # the NaN decision of the last step
         mean_loss = float(torch.stack(losses).mean()) if losses else float('nan')
         if epoch_end is not None:
             epoch_end(epoch, mean_loss, time.perf_counter() - t0)
