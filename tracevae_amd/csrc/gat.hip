@@ -1017,6 +1017,33 @@ __global__ __launch_bounds__(512) void gat_bwd_fused_kernel(AggArgs a) {
       acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
+    // A row whose only in-edge is its self-loop (a padded slot of the struct decoder: about half
+    // of its rows on the bench's traces, most of them on short real ones): the softmax over one
+    // edge has no gradient - alpha = 1, dpre = alpha (g - alpha g) = +0 exactly for any finite g -
+    // so ft[r], which only feeds g, is not read: two row transfers instead of three, with the
+    // bits of the general path (alpha * dout[r] through the same fma).
+    if (deg == 1 && a.indices[p0] == r) {
+      float al1[HT];
+      const int64_t rp = a.rev[p0];
+#pragma unroll
+      for (int h = 0; h < HT; ++h) al1[h] = (h < H) ? a.alpha_in[rp * H + h] : 0.f;
+      if (lane < H) {
+        a.dpre[p0 * H + lane] = 0.f;
+        a.der[r * H + lane] = 0.f;
+      }
+      float4 *orow = reinterpret_cast<float4 *>(a.dft + r * a.ld_dft);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        if (q < c4) {
+          const float4 o = f4_fma(sel_head<HT>(al1, hc[c]), d[c], acc[c]);
+          orow[q] = o;
+          dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+      }
+      continue;
+    }
+
     float sacc[HT], gkeep[HT];
 #pragma unroll
     for (int h = 0; h < HT; ++h) sacc[h] = gkeep[h] = 0.f;
