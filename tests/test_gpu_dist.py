@@ -112,6 +112,49 @@ def test_two_rank_step_equals_averaged_gradients(device, tmp_path, backend):
                for k in got[0]['buffers'] if k.endswith('running_mean'))
 
 
+def _nan_vote_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tracevae_amd.train import NANLossError
+    trainer = _trainer(device, world)
+    G, eps = _shard(rank)
+    trainer.step(G, eps=eps)                     # a healthy step first
+    trainer.finish()
+    if rank == 1:
+        with torch.no_grad():
+            trainer.flat.flat[3] = float('nan')  # this rank's loss becomes NaN
+    params, state = trainer.flat.flat.clone(), trainer.optimizer.state1.clone()
+    out = trainer.step(G, eps=eps)               # returns on both ranks, nothing is updated
+    raised = False
+    try:
+        trainer.finish()
+    except NANLossError:
+        raised = True
+    keep = ~torch.isnan(params)
+    torch.save({'raised': raised, 'loss_nan': bool(torch.isnan(out['loss'])),
+                'flag': float(trainer.flat.bucket[trainer.flat.flag_index]),
+                'params_kept': torch.equal(trainer.flat.flat[keep], params[keep]),
+                'state_kept': torch.equal(trainer.optimizer.state1, state)},
+               os.path.join(tmp, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_nan_on_one_rank_skips_the_update_on_every_rank_gloo(device, tmp_path):
+    """The NaN decision on the device with several ranks: the all-reduced count of NaN ranks
+    guards the update (`tv_optim_step_guarded`, guard_kind 2), so a NaN on rank 1 leaves
+    parameters and optimizer state untouched on BOTH ranks, and both raise at `finish()`."""
+    world, port = 2, 37000 + os.getpid() % 2000
+    _spawn_with_deadline(_nan_vote_worker, (world, port, str(tmp_path)), world)
+    r = [torch.load(tmp_path / f'r{i}.pt') for i in range(world)]
+    assert [x['loss_nan'] for x in r] == [False, True]
+    for x in r:
+        assert x['raised'] and x['flag'] == 1.0 and x['params_kept'] and x['state_kept'], x
+
+
 # ---------------------------------------------------------------------------------------
 # the whole data-parallel job: odd batch count, phase switch, sharded evaluation
 # ---------------------------------------------------------------------------------------
