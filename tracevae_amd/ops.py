@@ -4,7 +4,7 @@ autograd tape here; every operator body is a call into the HIP library (`hip.cal
 there is no other implementation to fall back to.
 """
 import math
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 from torch.autograd import Function
