@@ -703,3 +703,41 @@ def test_nan_decision_without_a_host_sync_per_step(device):
         keep = ~torch.isnan(params)
         assert torch.equal(tr.flat.flat[keep], params[keep]) and bool(torch.isnan(tr.flat.flat[3]))
         assert torch.equal(tr.optimizer.state1, state)
+
+
+def test_a_step_leaves_no_cyclic_garbage_that_holds_device_memory(device):
+    """What a step allocates is freed by reference counts when the step lets go of it - the
+    chain, its nets and the logits of every likelihood included (`VariationalChain.vi` keeps no
+    back-reference) - not whenever Python's cyclic collector happens to run."""
+    import gc
+    from tracevae_amd.batch import TraceGraphBatch
+    from tracevae_amd.train import Trainer
+    V, M = 60, 16
+    cfg, vae, store, flat, lr, P, buf, names = _setup(device, V, M, 16, 2, 12, seed=37)
+    B = len(flat)
+    trainer = Trainer(vae, cfg, world_size=1)
+
+    def one():
+        trainer.step(TraceGraphBatch.from_store(store, np.arange(B), M))
+    for _ in range(3):
+        one()
+    trainer.finish()
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        before = torch.cuda.memory_allocated()
+        for _ in range(3):
+            one()
+        trainer.finish()
+        torch.cuda.synchronize()
+        after = torch.cuda.memory_allocated()
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        gc.collect()
+        gc.set_debug(0)
+        held = [o for o in gc.garbage if isinstance(o, torch.Tensor) and o.is_cuda]
+        del gc.garbage[:]
+    finally:
+        gc.enable()
+    assert after == before, (before, after)
+    assert not held, [tuple(t.shape) for t in held]

@@ -134,7 +134,14 @@ class _VI(object):
 class VariationalChain(object):
     def __init__(self, q: BayesianNet, p: BayesianNet, latent_axis: Optional[int]):
         self.q, self.p, self.latent_axis = q, p, latent_axis
-        self.vi = _VI(self)
+
+    @property
+    def vi(self) -> _VI:
+        # made on access, not kept: a stored `_VI(self)` is a reference cycle chain <-> vi, and
+        # everything a step's chain reaches (the nets, their nodes, the logits of every
+        # likelihood: 26 MB at batch 64, 200 MB at 512) would then wait for Python's cyclic
+        # collector instead of being freed when the step lets go of the chain
+        return _VI(self)
 
     def log_joint(self) -> torch.Tensor:
         return _add_n([self.p[name].log_prob() for name in self.p])

@@ -10,7 +10,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-__all__ = ['lib', 'call', 'query', 'ptr', 'stream', 'library_path', 'header_path', 'SIGNATURES',
+__all__ = ['lib', 'call', 'query', 'array_type', 'ptr', 'stream', 'library_path', 'header_path', 'SIGNATURES',
            'HipLibraryError']
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -125,6 +125,19 @@ def call(name: str, *args) -> None:
     if rc != 0:
         msg = lib().tv_last_error().decode('utf-8', 'replace')
         raise HipLibraryError(f'{name} failed ({rc}): {msg}')
+
+
+_ARRAY_TYPES: Dict[tuple, type] = {}
+
+
+def array_type(ctype, n: int):
+    """`ctype * n`, kept: ctypes drops an array type when its last instance goes, and a type is a
+    reference cycle - a host table built per call would leave one for Python's cyclic collector
+    every time."""
+    t = _ARRAY_TYPES.get((ctype, n))
+    if t is None:
+        t = _ARRAY_TYPES[(ctype, n)] = ctype * n
+    return t
 
 
 _QUERIES: Dict[tuple, int] = {}

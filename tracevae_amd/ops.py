@@ -1469,7 +1469,7 @@ class _RealNVPLogProb(Function):
             raise hip.HipLibraryError(f'no RealNVP kernel for dim {dim} / hidden {hidden} / '
                                       f'{levels} levels')
         ws = torch.empty([size], dtype=_f32, device=z.device)
-        table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        table = hip.array_type(ctypes.c_void_p, len(params))(*[p.data_ptr() for p in params])
         logp = torch.empty(z.shape[:-1], dtype=_f32, device=z.device)
         with TIMER.region('realnvp_fwd', 0.0):
             hip.call('tv_realnvp_logprob_fwd', rows, levels, dim, hidden, slope, hip.ptr(z), table,
@@ -1494,8 +1494,8 @@ class _RealNVPLogProb(Function):
             grads.append(view if wanted else None)
             ptrs.append(view.data_ptr() if wanted else None)
         dz = torch.empty_like(z)
-        table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
-        gtable = (ctypes.c_void_p * len(params))(*ptrs)
+        table = hip.array_type(ctypes.c_void_p, len(params))(*[p.data_ptr() for p in params])
+        gtable = hip.array_type(ctypes.c_void_p, len(params))(*ptrs)
         with TIMER.region('realnvp_bwd', 0.0):
             hip.call('tv_realnvp_logprob_bwd', rows, levels, dim, hidden, slope, hip.ptr(z), table,
                      hip.ptr(dlogp), hip.ptr(ws), hip.ptr(dz), gtable)
@@ -1510,7 +1510,7 @@ def realnvp_actnorm_init(z, params, levels: int, hidden: int, slope: float) -> N
     params = [_check(p.detach(), 'flow parameter') for p in params]
     if len(params) != 9 * levels:
         raise ValueError(f'expected {9 * levels} flow parameters, got {len(params)}')
-    table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+    table = hip.array_type(ctypes.c_void_p, len(params))(*[p.data_ptr() for p in params])
     hip.call('tv_realnvp_actnorm_init', z.shape[0], levels, z.shape[1], hidden, float(slope),
              hip.ptr(z), table)
 
@@ -1542,11 +1542,11 @@ class _TrainLoss(Function):
                 raise ValueError(f'train_loss: latent of shape {tuple(z.shape)} for batch {batch}')
         out = torch.empty([3], dtype=_f32, device=vecs[0].device)
         ctx.tables = (
-            (ctypes.c_void_p * len(vecs))(*[v.data_ptr() for v in vecs]),
-            (ctypes.c_int * len(vecs))(*kinds),
-            (ctypes.c_void_p * max(len(zs), 1))(*[z.data_ptr() for z in zs]),
-            (ctypes.c_int64 * max(len(zs), 1))(*[z.shape[1] for z in zs]),
-            (ctypes.c_float * max(len(zs), 1))(*regs))
+            hip.array_type(ctypes.c_void_p, len(vecs))(*[v.data_ptr() for v in vecs]),
+            hip.array_type(ctypes.c_int, len(vecs))(*kinds),
+            hip.array_type(ctypes.c_void_p, max(len(zs), 1))(*[z.data_ptr() for z in zs]),
+            hip.array_type(ctypes.c_int64, max(len(zs), 1))(*[z.shape[1] for z in zs]),
+            hip.array_type(ctypes.c_float, max(len(zs), 1))(*regs))
         vt, kt, zt, dt, rt = ctx.tables
         hip.call('tv_train_loss_fwd', batch, len(vecs), vt, kt, len(zs), zt, dt, rt,
                  hip.ptr(l2_value), float(l2_reg), float(beta), hip.ptr(out))
@@ -1570,9 +1570,9 @@ class _TrainLoss(Function):
         dloss = _check(dloss.reshape(1), 'dloss')
         grads = [torch.empty_like(t) if w else None for t, w in zip(saved, need)]
         vt, kt, zt, dt, rt = ctx.tables
-        gv = (ctypes.c_void_p * n_vec)(*[g.data_ptr() if g is not None else None
+        gv = hip.array_type(ctypes.c_void_p, n_vec)(*[g.data_ptr() if g is not None else None
                                          for g in grads[:n_vec]])
-        gz = (ctypes.c_void_p * max(n_z, 1))(*[g.data_ptr() if g is not None else None
+        gz = hip.array_type(ctypes.c_void_p, max(n_z, 1))(*[g.data_ptr() if g is not None else None
                                                for g in grads[n_vec:]])
         hip.call('tv_train_loss_bwd', batch, n_vec, vt, kt, gv, n_z, zt, dt, rt, gz, beta,
                  hip.ptr(dloss))
