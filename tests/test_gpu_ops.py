@@ -1443,3 +1443,55 @@ def test_gemm_takes_a_prepared_image_of_b(device, m, n, k, trans_b):
     assert rel_err(want, a @ (b.t() if trans_b else b)) < 1e-5
     with pytest.raises(hip.HipLibraryError):
         product(m, n, k, trans_b, a, image, b.stride(0), box, 4 - form, got)
+
+
+def test_batched_preparation_and_guarded_update_refuse_what_they_cannot_take(device):
+    """Error paths of this round's entry points: more operands than a launch takes, a guard kind
+    without a guard, and a `guard_host` that is not pinned host memory (refused by the host-side
+    lookup of its device address - never a faulting store from the kernel)."""
+    import ctypes
+    from tracevae_amd import hip
+    lib = hip.lib()
+    n = 33
+    i64, i32, ptrs = ctypes.c_int64 * n, ctypes.c_int * n, ctypes.c_void_p * n
+    w = torch.randn(128, 128, device=device)
+    img = torch.empty([hip.query('tv_gemm_prepared_b_bytes', 4096, 128, 128)], dtype=torch.uint8, device=device)
+    box = torch.zeros(256, device=device)
+    args = (i64(*[4096] * n), i64(*[128] * n), i64(*[128] * n), i32(*[0] * n), ptrs(*[w.data_ptr()] * n),
+            i64(*[128] * n), ptrs(*[box.data_ptr()] * n), ptrs(*[img.data_ptr()] * n))
+    assert lib.tv_gemm_prepare_b_batch(n, *args, hip.stream()) != 0
+    assert b'tv_gemm_prepare_b_batch' in lib.tv_last_error()
+    m = 17
+    i64m, ptrm = ctypes.c_int64 * m, ctypes.c_void_p * m
+    a = torch.randn(2, 64, device=device)
+    wx = torch.empty(128 + 4, 128, device=device)
+    assert lib.tv_gat_fc_score_weight_batch(
+        m, i64m(*[2] * m), i64m(*[64] * m), i64m(*[128] * m), ptrm(*[w.data_ptr()] * m),
+        ptrm(*[a.data_ptr()] * m), ptrm(*[a.data_ptr()] * m), ptrm(*[wx.data_ptr()] * m),
+        ptrm(*[box.data_ptr()] * m), hip.stream()) != 0
+    assert b'tv_gat_fc_score_weight_batch' in lib.tv_last_error()
+
+    p = torch.ones(64, device=device)
+    g = torch.ones(64, device=device)
+    s1 = torch.zeros(64, device=device)
+    guard = torch.zeros(1, device=device)
+    common = (0, 64, p.data_ptr(), g.data_ptr(), s1.data_ptr(), None, None, 0.0, 1e-3, 0.0, 0.99, 1e-8, 1)
+    assert lib.tv_optim_step_guarded(*common, None, 1, None, hip.stream()) != 0          # kind, no guard
+    assert lib.tv_optim_step_guarded(*common, guard.data_ptr(), 0, None, hip.stream()) != 0   # guard, no kind
+    pageable = torch.zeros(1)                                                             # not pinned
+    assert lib.tv_optim_step_guarded(*common, guard.data_ptr(), 2, pageable.data_ptr(), hip.stream()) != 0
+    torch.cuda.synchronize()
+    assert torch.equal(p, torch.ones(64, device=device))          # none of the refused calls ran
+    # the accepted form: guard 0 -> the update runs and the pinned scalar receives the guard
+    pinned = torch.full([1], 7.0).pin_memory()
+    assert lib.tv_optim_step_guarded(*common, guard.data_ptr(), 2, pinned.data_ptr(), hip.stream()) == 0
+    torch.cuda.synchronize()
+    assert float(pinned[0]) == 0.0 and not torch.equal(p, torch.ones(64, device=device))
+    # a non-zero guard of kind 2, a NaN of kind 1: nothing moves
+    before = p.clone()
+    guard.fill_(1.0)
+    assert lib.tv_optim_step_guarded(*common, guard.data_ptr(), 2, pinned.data_ptr(), hip.stream()) == 0
+    guard.fill_(float('nan'))
+    assert lib.tv_optim_step_guarded(*common, guard.data_ptr(), 1, pinned.data_ptr(), hip.stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(p, before) and math.isnan(float(pinned[0]))

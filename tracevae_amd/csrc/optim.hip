@@ -212,7 +212,13 @@ static int optim_step(const char *who, int kind, int64_t n, float *param, const 
     // the device's address of the pinned host scalar; fails (instead of faulting in the kernel)
     // for memory that is not mapped
     void *mapped = nullptr;
-    TV_HIP(hipHostGetDevicePointer(&mapped, guard_host, 0));
+    const hipError_t e = hipHostGetDevicePointer(&mapped, guard_host, 0);
+    if (e != hipSuccess || !mapped) {
+      (void)hipGetLastError();   // the refusal is ours to report: leave no sticky HIP error behind
+      tv_set_error("tv_optim_step_guarded: guard_host is not pinned host memory (%s)",
+                   hipGetErrorString(e));
+      return TV_ERR_INVALID;
+    }
     guard_copy = (float *)mapped;
   }
   float bc1 = 1.0f, bc2s = 1.0f;

@@ -655,6 +655,8 @@ def prepare_gat_layers(layers, rows: int):
             if (f_fwd < 0 or f_bwd < 0 or k % 4 or (k + 15) // 16 * heads > 256
                     or not (weight.is_contiguous() and attn_l.is_contiguous() and attn_r.is_contiguous())):
                 continue
+            if len(todo) == 16:         # what one tv_gat_fc_score_weight_batch launch takes; the
+                break                   # layers beyond it prepare their own weights
             todo.append((i, weight, attn_l, attn_r, heads, feats, k, width, f_fwd, f_bwd))
         ent = {'n': len(todo), 'out': [None] * len(layers)}
         if todo:
